@@ -1,0 +1,107 @@
+"""Replays a tests/golden/*.npz scenario (generated from the reference's own
+QuantK/QuantV classes by tests/golden/gen_golden.py) through any pair of
+QuantK/QuantV-compatible classes and returns the same set of outputs."""
+import math
+
+import numpy as np
+import torch
+
+H, HD, C = 32, 128, 4096
+
+
+def load(path):
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
+
+
+def quantizer(g):
+    return (g["q_upper"], g["q_lower"], [g["q_centroids"]])
+
+
+def replay(g, QuantK, QuantV, device="cpu", v_topk_on_host=True):
+    bits, sparse, sinks = int(g["bits"]), bool(g["include_sparse"]), int(g["sinks"])
+    S, steps, max_len, theta = int(g["S"]), int(g["steps"]), int(g["max_len"]), float(g["theta"])
+    dev = torch.device(device)
+    k_all = torch.from_numpy(g["k_all"]).to(dev)
+    v_all = torch.from_numpy(g["v_all"]).to(dev)
+    q_all = torch.from_numpy(g["q_all"]).to(dev)
+    kc = QuantK(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
+                include_sparse=sparse, sparsity_threshold=0.99, rope_theta=theta, first_few_fp16=sinks)
+    vc = QuantV(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
+                include_sparse=sparse, sparsity_threshold=0.99, first_few_fp16=sinks)
+    kc.load_lookup_table(quantizer(g), include_sparse=sparse, sparsity_threshold=0.99)
+    vc.load_lookup_table(quantizer(g), include_sparse=sparse, sparsity_threshold=0.99)
+    out = {"k_lookup_table": kc.lookup_table, "k_thr_upper": kc.outlier_threshold_upper,
+           "k_thr_lower": kc.outlier_threshold_lower, "v_lut": vc.lut}
+    thr = int(((1 - 0.99) / 2) * C) + 2
+    if sparse and S > 0:
+        ks = k_all[sinks:sinks + S].view(S, H, HD).permute(1, 2, 0)
+        vs = v_all[sinks:sinks + S].view(S, H, HD).permute(1, 2, 0)
+        kc.parallel_pack(ks)
+        kc.klen += sinks
+        if v_topk_on_host:
+            vflat = v_all[sinks:sinks + S].float()
+            uv, ui = torch.topk(vflat, thr, dim=-1)
+            lv, li = torch.topk(vflat, thr, dim=-1, largest=False)
+            vc.parallel_pack(vs, uv, ui, lv, li)
+        else:
+            vc.parallel_pack(vs, None, None, None, None)
+        vc.vlen += sinks
+    else:
+        kc.klen += sinks
+        vc.vlen += sinks
+        S = 0
+    for i in range(steps):
+        t = sinks + S + i
+        q = q_all[t].view(H, 1, HD)
+        k = k_all[t].view(1, H, 1, HD)
+        scores = kc.forward_fused_sparse(q, k)
+        out["score_%d" % i] = scores
+        # feed the golden probabilities so V is checked independently of K rounding
+        aw = torch.from_numpy(g["prob_%d" % i]).to(dev)
+        v = v_all[t].view(1, H, 1, HD)
+        if sparse and v_topk_on_host:
+            vf = v.flatten().float()
+            uv, ui = torch.topk(vf, thr)
+            lv, li = torch.topk(vf, thr, largest=False)
+            o = vc.forward_fused_sparse(aw, v, uv, ui, lv, li)
+        else:
+            o = vc.forward_fused_sparse(aw, v, None, None, None, None)
+        out["attn_%d" % i] = o
+    L = kc.klen - sinks
+    out["kcache"] = kc.kcache[:, :, :L]
+    out["vcache"] = vc.vcache[:, :, :L]
+    out["v_lookup_table"] = vc.lookup_table[:L]
+    if sparse:
+        out["k_outliers"] = kc.outliers[:L]
+        out["k_outlier_indices"] = kc.outlier_indices[:L]
+        out["v_outliers"] = vc.outliers[:L]
+        out["v_outlier_indices"] = vc.outlier_indices[:L]
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+EXACT_KEYS = ["k_lookup_table", "k_thr_upper", "k_thr_lower", "v_lut", "kcache", "vcache", "v_lookup_table",
+              "k_outliers", "k_outlier_indices", "v_outliers", "v_outlier_indices"]
+
+
+def compare(g, out, exact_scores=False, rtol=1e-3):
+    """bit-exact on packed caches / LUTs / outlier rows; scores and outputs within
+    1e-3 relative (of the row's max magnitude) in fp16, the north-star tolerance."""
+    for k in EXACT_KEYS:
+        if k in g:
+            a, b = g[k], out[k]
+            assert a.shape == b.shape, (k, a.shape, b.shape)
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                  b.view(np.uint32) if b.dtype == np.float32 else b), "mismatch in " + k
+    for k in g:
+        if k.startswith("score_") or k.startswith("attn_"):
+            a = g[k].astype(np.float32)
+            b = out[k].astype(np.float32)
+            assert a.shape == b.shape, (k, a.shape, b.shape)
+            if exact_scores:
+                assert np.array_equal(a, b), "mismatch in " + k
+            else:
+                scale = np.abs(a).max(axis=-1, keepdims=True) + 1e-6
+                err = np.abs(a - b) / scale
+                # fp16 output: allow one fp16 ulp of the row scale on top of rtol
+                assert err.max() <= rtol + 2 ** -10, (k, float(err.max()))
