@@ -1,0 +1,172 @@
+/*
+ * kvq.h -- C ABI of the MI355X-native KVQuant hot path (libkvq.so).
+ *
+ * This is the drop-in boundary: plain device pointers, sizes, scalars and a
+ * hipStream_t (passed as void*).  No torch types.  Every entry point replaces
+ * one family of functions of the reference's pybind11 module `quant_cuda`
+ * (KCPP = /root/reference/deployment/kvquant/quant_cuda.cpp, kernels in
+ * KCU = /root/reference/deployment/kvquant/quant_cuda_kernel.cu), with
+ * `bits` (2, 3 or 4) as a parameter instead of three copies.  INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on the current HIP device unless the
+ *     name says host; buffers are contiguous and owned by the caller;
+ *   - cache `mat`: int32 [H][hd/32*bits][max_len], token index contiguous,
+ *     bit layout of KCU:1240-1244 (4b), 1395-1424 (3b), 2712-2716 (2b);
+ *   - K look-up table `lut`: float [H][hd][2^bits] (per channel);
+ *   - V look-up table `lut_rows`: float [max_len][2^bits] (per token);
+ *   - sparse buffers: `outliers` float [max_len][n_out], `outlier_idx` int32
+ *     [max_len][n_out], global channel indices ascending within a row;
+ *   - head_dim must be 128 for the score/mix kernels (the reference kernels
+ *     hard-code BLOCKWIDTH = 128 = head_dim, KCU:43, 3101), any multiple of 32
+ *     for the append/pack kernels;
+ *   - every function is asynchronous on `stream` and returns 0 on success or
+ *     a negative KVQ_E* code (kvq_strerror); nothing is allocated or freed.
+ *   - the reference asserts on shapes and otherwise faults; here violated
+ *     preconditions are reported as KVQ_EINVAL before any launch.
+ */
+#ifndef KVQ_H
+#define KVQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVQ_OK 0
+#define KVQ_EINVAL (-1)    /* bad argument (null pointer, unsupported bits / head_dim / size) */
+#define KVQ_ELAUNCH (-2)   /* hipLaunch / runtime error, see kvq_last_hip_error() */
+#define KVQ_EWORKSPACE (-3) /* workspace missing or too small */
+
+int kvq_version(void);
+const char *kvq_strerror(int code);
+/* last hipError_t seen by a failing call on this thread (0 = none) */
+int kvq_last_hip_error(void);
+
+/* ---- append one token -------------------------------------------------- */
+
+/* vecquant{2,3,4}appendvecK (KCPP:5-33; KCU:1167-1245, 1322-1425, 1528-1607):
+ * code[c] = argmin_v |lut[c][v] - x[c]| (first minimum wins), packed into
+ * column `col`, which must be zero. */
+int kvq_append_k(int bits, int32_t *mat, const float *lut, const float *x,
+                 int H, int hd, int64_t max_len, int64_t col, void *stream);
+
+/* vecquant{2,3,4}appendvecV (KCPP:99-124; KCU:1248-1320, 1427-1526,
+ * 1609-1682): as above with the per-token row lut_rows[col]. */
+int kvq_append_v(int bits, int32_t *mat, const float *lut_rows, const float *x,
+                 int H, int hd, int64_t max_len, int64_t col, void *stream);
+
+/* vecquant{2,3,4}appendvecKsparse (KCPP:35-43, 58-63, 78-83; KCU:1684-1781,
+ * 2104-2227, 2620-2717): append_k plus
+ * rescaled[c] = (x[c] - (hi[c]+lo[c])/2) / ((hi[c]-lo[c])/2). */
+int kvq_append_k_sparse(int bits, int32_t *mat, const float *lut, const float *x,
+                        float *rescaled, const float *lo, const float *hi,
+                        int H, int hd, int64_t max_len, int64_t col, void *stream);
+
+/* vecquant{2,3,4}appendvecVsparse (KCPP:126-134, 150-155, 170-175;
+ * KCU:2011-2102, 2369-2486, 2947-3038): code = (x<lo || x>hi) ? 7/3/1 :
+ * argmin over lut_rows[col].  (The reference's `zeropoint` argument is unused
+ * by its kernel and therefore not part of this ABI.) */
+int kvq_append_v_sparse(int bits, int32_t *mat, const float *lut_rows,
+                        const float *x, float lo, float hi, int H, int hd,
+                        int64_t max_len, int64_t col, void *stream);
+
+/* ---- pack S prompt tokens (prefill) ------------------------------------ */
+
+/* vecquant{2,3,4}appendvecKsparseParallel (KCPP:45-53, 65-73, 85-93;
+ * KCU:1783-1898, 2229-2366, 2719-2834): x and rescaled are [H][hd][S]
+ * (token contiguous); writes columns col0 .. col0+S-1 (reference: col0 = 0). */
+int kvq_pack_k_sparse_parallel(int bits, int32_t *mat, const float *lut,
+                               const float *x, float *rescaled, const float *lo,
+                               const float *hi, int H, int hd, int64_t S,
+                               int64_t max_len, int64_t col0, void *stream);
+
+/* vecquant{2,3,4}appendvecVsparseParallel (KCPP:136-144, 157-165, 177-185;
+ * KCU:1900-2009, 2488-2618, 2836-2945): per-token rows lut_rows[col0+t] and
+ * per-token thresholds lo[t], hi[t] (t < S). */
+int kvq_pack_v_sparse_parallel(int bits, int32_t *mat, const float *lut_rows,
+                               const float *x, const float *lo, const float *hi,
+                               int H, int hd, int64_t S, int64_t max_len,
+                               int64_t col0, void *stream);
+
+/* ---- decode matvecs ------------------------------------------------------ */
+
+/* vecquant{b}matmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt and
+ * ..._opt2 (KCPP:188-212 ...; KCU:3040-3209, 3437-3622, 473-521):
+ *   mul[b][h][t] (+)= sum_k Khat[h][k][t] * (cos(a)*q[b][h][k]
+ *                       + sgn_k*sin(a)*q[b][h][(k+64)%128]),
+ *   a = fl32(theta^(-2(k%64)/128) * (t+pos_offset)),
+ * Khat = LUT value + the token's sparse residuals when outliers != NULL (the
+ * sparse part only for b = 0, as the reference).  q: float [q_len][H][128];
+ * mul: float [q_len][H][L].  accumulate != 0: add into mul (the reference's
+ * pre-zeroed contract); 0: overwrite. */
+int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul,
+                const float *lut, int q_len, int H, int hd, int64_t L,
+                int64_t max_len, float rope_theta, int pos_offset,
+                const float *outliers, const int32_t *outlier_idx, int n_out,
+                int accumulate, void *stream);
+
+/* vecquant{b}matmul_nuq_perchannel_transposed_mha_batched_fused_opt and
+ * ..._opt2 (KCPP:214-238 ...; KCU:3211-3433, 3491-3538, 3625-3690, 437-470):
+ *   mul[b][h][c] (+)= sum_t Vhat[h][c][t] * p[b][h][t]
+ * p: float [q_len][H][L]; mul: float [q_len][H][128].  Needs a device
+ * workspace of kvq_mix_v_workspace_bytes(...) bytes (partial sums; no atomics,
+ * deterministic). */
+size_t kvq_mix_v_workspace_bytes(int bits, int q_len, int H, int hd, int64_t L);
+int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul,
+              const float *lut_rows, int q_len, int H, int hd, int64_t L,
+              int64_t max_len, const float *outliers, const int32_t *outlier_idx,
+              int n_out, int accumulate, void *workspace, size_t workspace_bytes,
+              void *stream);
+
+/* ---- GPU-resident outlier selection (replaces the reference's CPU topk) -- */
+
+/* One call = vecquant{b}appendvecKsparse + the host glue of
+ * QuantK.forward_fused_sparse (modeling_llama.py:706-751): top-thr_k largest
+ * and smallest rescaled values, residual = x - lut_off[c][n-1] / lut_off[c][0],
+ * zeroed where |rescaled| <= 1, sorted by channel, stored to row `col` of
+ * outliers / outlier_idx (width 2*thr_k).  lut_off = lut, or the Q-Norm table.
+ * Ties at the selection boundary: the lowest channel index wins. */
+int kvq_append_k_fused(int bits, int32_t *mat, const float *lut,
+                       const float *lut_off, const float *x, const float *lo,
+                       const float *hi, float *outliers, int32_t *outlier_idx,
+                       int thr_k, int H, int hd, int64_t max_len, int64_t col,
+                       void *stream);
+
+/* One call = the V top-(thr_k+1) selection of modeling_llama.py:1537-1545,
+ * the per-token LUT row lut_sorted*sf+off (1086-1114), vecquant{b}appendvecVsparse
+ * and the sparse row (1168-1176). lut_sorted: float [2^bits] ascending. */
+int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows,
+                       const float *lut_sorted, const float *x, float *outliers,
+                       int32_t *outlier_idx, int thr_k, int H, int hd,
+                       int64_t max_len, int64_t col, void *stream);
+
+/* Prefill counterparts for S tokens, x [H][hd][S]:
+ * K: pack + rescale + outlier rows col0..col0+S-1 (modeling_llama.py:879-972);
+ * needs a float workspace of H*hd*S elements for the rescaled values.
+ * V: top-k, LUT rows, pack, outlier rows (modeling_llama.py:1294-1382). */
+int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut,
+                     const float *lut_off, const float *x, const float *lo,
+                     const float *hi, float *outliers, int32_t *outlier_idx,
+                     int thr_k, int H, int hd, int64_t S, int64_t max_len,
+                     int64_t col0, float *rescaled_ws, void *stream);
+int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows,
+                     const float *lut_sorted, const float *x, float *outliers,
+                     int32_t *outlier_idx, int thr_k, int H, int hd, int64_t S,
+                     int64_t max_len, int64_t col0, void *stream);
+
+/* softmax of modeling_llama.py:1972-1977 fused into one launch:
+ * in: fp16 scores [H][n_cols] (optionally preceded by n_sink fp16 sink scores
+ * [H][n_sink], already scaled), out: fp16 probabilities [H][n_sink+n_cols]:
+ * half(score) / sqrt(hd) in fp16, softmax in fp32, rounded to fp16. */
+int kvq_softmax_f16(const uint16_t *scores, const uint16_t *sink_scores,
+                    uint16_t *probs, int H, int64_t n_cols, int n_sink,
+                    float inv_sqrt_hd, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVQ_H */

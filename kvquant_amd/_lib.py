@@ -1,0 +1,64 @@
+"""ctypes binding of libkvq.so (include/kvq.h).  There is NO fallback: if the
+library is missing or a call fails this raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkvq.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/kvq.h one to one
+SIGNATURES = {
+    "kvq_version": (_i, []),
+    "kvq_strerror": (ctypes.c_char_p, [_i]),
+    "kvq_last_hip_error": (_i, []),
+    "kvq_append_k": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
+    "kvq_append_v": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
+    "kvq_append_k_sparse": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
+    "kvq_append_v_sparse": (_i, [_i, _vp, _vp, _vp, _f, _f, _i, _i, _i64, _i64, _vp]),
+    "kvq_pack_k_sparse_parallel": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _vp]),
+    "kvq_pack_v_sparse_parallel": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _vp]),
+    "kvq_score_k": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp]),
+    "kvq_mix_v_workspace_bytes": (_sz, [_i, _i, _i, _i, _i64]),
+    "kvq_mix_v": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "kvq_append_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "kvq_append_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "kvq_pack_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _vp]),
+    "kvq_pack_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
+    "kvq_softmax_f16": (_i, [_vp, _vp, _vp, _i, _i64, _i, _f, _vp]),
+}
+
+_lib = None
+
+
+class KvqError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KvqError(
+                "kvquant_amd: %s not found -- build it with `python -m kvquant_amd.build` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        l = lib()
+        msg = l.kvq_strerror(rc).decode()
+        raise KvqError("%s failed: %s (code %d, hip error %d)" % (what, msg, rc, l.kvq_last_hip_error()))

@@ -1,0 +1,118 @@
+// Shared device helpers for the gfx950 KVQuant kernels.
+// Built with -ffp-contract=off: the places that must round like the reference
+// (LUT rows, rescale, nearest-code compare) are plain mul/add/div sequences;
+// everything that may fuse uses fmaf explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kvq.h"
+
+namespace kvq {
+
+constexpr int kWave = 64;
+constexpr int kHeadDim = 128;  // score / mix kernels (reference BLOCKWIDTH, KCU:43)
+
+// words of packed cache per 32 channels == bits
+template <int BITS>
+struct Fmt {
+  static constexpr int kN = 1 << BITS;               // LUT entries
+  static constexpr int kWordsPer32 = BITS;           // int32 words per 32 channels
+  static constexpr int kWordsPerHead = kHeadDim / 32 * BITS;
+  static constexpr unsigned kZeroCode = BITS == 4 ? 7u : (BITS == 3 ? 3u : 1u);  // KCU:2084/2442/3020
+};
+
+// argmin_v |lut[v]-x|, strict '<' from v=0 (KCU:1222-1237)
+template <int N>
+__device__ __forceinline__ unsigned nearest_code(const float (&lut)[N], float x) {
+  unsigned best = 0;
+  float prev = fabsf(lut[0] - x);
+#pragma unroll
+  for (int v = 1; v < N; v++) {
+    float d = fabsf(lut[v] - x);
+    if (d < prev) {
+      prev = d;
+      best = (unsigned)v;
+    }
+  }
+  return best;
+}
+
+// Pack 32 codes (one 32-channel group) into BITS words; layout of
+// KCU:1240-1244 (4b), 1395-1424 (3b), 2712-2716 (2b).
+template <int BITS>
+__device__ __forceinline__ void pack32(const unsigned (&code)[32], uint32_t (&w)[BITS]) {
+#pragma unroll
+  for (int i = 0; i < BITS; i++) w[i] = 0;
+  if constexpr (BITS == 4) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) w[i / 8] |= code[i] << (4 * (i % 8));
+  } else if constexpr (BITS == 2) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) w[i / 16] |= code[i] << (2 * (i % 16));
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      if (i == 10) {
+        w[0] |= code[i] << 30;
+        w[1] |= code[i] >> 2;
+      } else if (i == 21) {
+        w[1] |= code[i] << 31;
+        w[2] |= code[i] >> 1;
+      } else {
+        w[i / 11] |= code[i] << ((i * 3) % 32);
+      }
+    }
+  }
+}
+
+// code of channel i (0..31, compile-time) of a 32-channel group held in BITS words.
+template <int BITS, int I>
+__device__ __forceinline__ unsigned code_of(const uint32_t (&w)[BITS]) {
+  if constexpr (BITS == 4) {
+    return (w[I / 8] >> (4 * (I % 8))) & 0xfu;
+  } else if constexpr (BITS == 2) {
+    return (w[I / 16] >> (2 * (I % 16))) & 0x3u;
+  } else {
+    if constexpr (I < 10) return (w[0] >> (3 * I)) & 0x7u;
+    else if constexpr (I == 10) return ((w[0] >> 30) & 0x3u) | ((w[1] & 0x1u) << 2);
+    else if constexpr (I < 21) return (w[1] >> ((3 * I) % 32)) & 0x7u;
+    else if constexpr (I == 21) return ((w[1] >> 31) & 0x1u) | ((w[2] & 0x3u) << 1);
+    else return (w[2] >> ((3 * I) % 32)) & 0x7u;
+  }
+}
+
+// compile-time loop helper
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---- sincos of a (possibly huge) fp32 angle, |error| ~1e-6 ----------------
+// The reference evaluates cosf/sinf(fl32(theta_k * pos)) (KCU:3122-3123); the
+// rounding of the product is part of the contract, so the
+// caller forms `ang` exactly that way and this only has to be an accurate
+// sincos of that float.  x/(2*pi) is split hi/lo with FMAs (C1+C2 = 1/(2*pi) to
+// ~2^-50) so that the fractional revolution is exact to ~1e-7 for any
+// |ang| < 2^31; the hardware v_sin/v_cos take revolutions.
+__device__ __forceinline__ void sincos_rev(float ang, float &s, float &c) {
+  constexpr float C1 = 0.15915494f;         // fl32(1/(2*pi)) = 0x3E22F983
+  constexpr float C2 = 6.4206382e-9f;       // 1/(2*pi) - C1
+  float hi = ang * C1;
+  float e = fmaf(ang, C1, -hi);             // exact rounding error of hi
+  float lo = fmaf(ang, C2, e);
+  float r = __builtin_amdgcn_fractf(hi) + lo;
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
+
+struct RopeFreqs {
+  float f[kHeadDim / 2];  // theta^(-2j/128), j = 0..63, computed on the host
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+}  // namespace kvq

@@ -1,0 +1,51 @@
+"""Synthetic inputs shared by the parity tests (seeded)."""
+import numpy as np
+import torch
+
+H, HD, C = 32, 128, 4096
+
+
+def centroids(bits, seed=0):
+    n = 2 ** bits
+    g = torch.Generator().manual_seed(100 + bits + seed)
+    c = torch.sort(torch.rand(n, generator=g) * 2 - 1).values
+    c[0], c[-1] = -0.98, 0.97
+    return c.float()
+
+
+def k_tables(bits, H=H, hd=HD, seed=0):
+    """per-channel LUT [H,hd,n] (rows ascending), thresholds lo/hi [C] (fp16-representable)."""
+    g = torch.Generator().manual_seed(seed)
+    Cn = H * hd
+    scale = torch.exp(0.5 * torch.randn(Cn, generator=g))
+    shift = 0.3 * torch.randn(Cn, generator=g)
+    hi = (shift + 2.6 * scale).half().float()
+    lo = (shift - 2.6 * scale).half().float()
+    off = ((hi.half() + lo.half()) / 2).float()
+    rng = ((hi.half() - lo.half()) / 2).float()
+    lut = centroids(bits).unsqueeze(0) * rng.unsqueeze(1) + off.unsqueeze(1)
+    return lut.reshape(H, hd, -1).contiguous(), lo.contiguous(), hi.contiguous(), scale, shift
+
+
+def k_tokens(S, scale, shift, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(S, scale.numel(), generator=g) * scale + shift
+    m = torch.rand(S, scale.numel(), generator=g) < 0.01
+    x[m] *= 4.0
+    return x.half().float()
+
+
+def v_tokens(S, Cn=C, seed=2):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(S, Cn, generator=g)
+    m = torch.rand(S, Cn, generator=g) < 0.01
+    x[m] *= 5.0
+    return x.half().float()
+
+
+def rel_err(a, b, dim=-1):
+    """max |a-b| relative to the max magnitude of the reference row"""
+    a = a.double()
+    b = b.double()
+    scale = b.abs().amax(dim=dim, keepdim=True).clamp_min(1e-12)
+    return float(((a - b).abs() / scale).max())
