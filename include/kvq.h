@@ -32,6 +32,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#if defined(__GNUC__)
+#define KVQ_API __attribute__((visibility("default")))
+#else
+#define KVQ_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -41,28 +47,28 @@ extern "C" {
 #define KVQ_ELAUNCH (-2)   /* hipLaunch / runtime error, see kvq_last_hip_error() */
 #define KVQ_EWORKSPACE (-3) /* workspace missing or too small */
 
-int kvq_version(void);
-const char *kvq_strerror(int code);
+KVQ_API int kvq_version(void);
+KVQ_API const char *kvq_strerror(int code);
 /* last hipError_t seen by a failing call on this thread (0 = none) */
-int kvq_last_hip_error(void);
+KVQ_API int kvq_last_hip_error(void);
 
 /* ---- append one token -------------------------------------------------- */
 
 /* vecquant{2,3,4}appendvecK (KCPP:5-33; KCU:1167-1245, 1322-1425, 1528-1607):
  * code[c] = argmin_v |lut[c][v] - x[c]| (first minimum wins), packed into
  * column `col`, which must be zero. */
-int kvq_append_k(int bits, int32_t *mat, const float *lut, const float *x,
+KVQ_API int kvq_append_k(int bits, int32_t *mat, const float *lut, const float *x,
                  int H, int hd, int64_t max_len, int64_t col, void *stream);
 
 /* vecquant{2,3,4}appendvecV (KCPP:99-124; KCU:1248-1320, 1427-1526,
  * 1609-1682): as above with the per-token row lut_rows[col]. */
-int kvq_append_v(int bits, int32_t *mat, const float *lut_rows, const float *x,
+KVQ_API int kvq_append_v(int bits, int32_t *mat, const float *lut_rows, const float *x,
                  int H, int hd, int64_t max_len, int64_t col, void *stream);
 
 /* vecquant{2,3,4}appendvecKsparse (KCPP:35-43, 58-63, 78-83; KCU:1684-1781,
  * 2104-2227, 2620-2717): append_k plus
  * rescaled[c] = (x[c] - (hi[c]+lo[c])/2) / ((hi[c]-lo[c])/2). */
-int kvq_append_k_sparse(int bits, int32_t *mat, const float *lut, const float *x,
+KVQ_API int kvq_append_k_sparse(int bits, int32_t *mat, const float *lut, const float *x,
                         float *rescaled, const float *lo, const float *hi,
                         int H, int hd, int64_t max_len, int64_t col, void *stream);
 
@@ -70,7 +76,7 @@ int kvq_append_k_sparse(int bits, int32_t *mat, const float *lut, const float *x
  * KCU:2011-2102, 2369-2486, 2947-3038): code = (x<lo || x>hi) ? 7/3/1 :
  * argmin over lut_rows[col].  (The reference's `zeropoint` argument is unused
  * by its kernel and therefore not part of this ABI.) */
-int kvq_append_v_sparse(int bits, int32_t *mat, const float *lut_rows,
+KVQ_API int kvq_append_v_sparse(int bits, int32_t *mat, const float *lut_rows,
                         const float *x, float lo, float hi, int H, int hd,
                         int64_t max_len, int64_t col, void *stream);
 
@@ -79,7 +85,7 @@ int kvq_append_v_sparse(int bits, int32_t *mat, const float *lut_rows,
 /* vecquant{2,3,4}appendvecKsparseParallel (KCPP:45-53, 65-73, 85-93;
  * KCU:1783-1898, 2229-2366, 2719-2834): x and rescaled are [H][hd][S]
  * (token contiguous); writes columns col0 .. col0+S-1 (reference: col0 = 0). */
-int kvq_pack_k_sparse_parallel(int bits, int32_t *mat, const float *lut,
+KVQ_API int kvq_pack_k_sparse_parallel(int bits, int32_t *mat, const float *lut,
                                const float *x, float *rescaled, const float *lo,
                                const float *hi, int H, int hd, int64_t S,
                                int64_t max_len, int64_t col0, void *stream);
@@ -87,7 +93,7 @@ int kvq_pack_k_sparse_parallel(int bits, int32_t *mat, const float *lut,
 /* vecquant{2,3,4}appendvecVsparseParallel (KCPP:136-144, 157-165, 177-185;
  * KCU:1900-2009, 2488-2618, 2836-2945): per-token rows lut_rows[col0+t] and
  * per-token thresholds lo[t], hi[t] (t < S). */
-int kvq_pack_v_sparse_parallel(int bits, int32_t *mat, const float *lut_rows,
+KVQ_API int kvq_pack_v_sparse_parallel(int bits, int32_t *mat, const float *lut_rows,
                                const float *x, const float *lo, const float *hi,
                                int H, int hd, int64_t S, int64_t max_len,
                                int64_t col0, void *stream);
@@ -103,7 +109,7 @@ int kvq_pack_v_sparse_parallel(int bits, int32_t *mat, const float *lut_rows,
  * sparse part only for b = 0, as the reference).  q: float [q_len][H][128];
  * mul: float [q_len][H][L].  accumulate != 0: add into mul (the reference's
  * pre-zeroed contract); 0: overwrite. */
-int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul,
+KVQ_API int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul,
                 const float *lut, int q_len, int H, int hd, int64_t L,
                 int64_t max_len, float rope_theta, int pos_offset,
                 const float *outliers, const int32_t *outlier_idx, int n_out,
@@ -115,56 +121,12 @@ int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul,
  * p: float [q_len][H][L]; mul: float [q_len][H][128].  Needs a device
  * workspace of kvq_mix_v_workspace_bytes(...) bytes (partial sums; no atomics,
  * deterministic). */
-size_t kvq_mix_v_workspace_bytes(int bits, int q_len, int H, int hd, int64_t L);
-int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul,
+KVQ_API size_t kvq_mix_v_workspace_bytes(int bits, int q_len, int H, int hd, int64_t L);
+KVQ_API int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul,
               const float *lut_rows, int q_len, int H, int hd, int64_t L,
               int64_t max_len, const float *outliers, const int32_t *outlier_idx,
               int n_out, int accumulate, void *workspace, size_t workspace_bytes,
               void *stream);
-
-/* ---- GPU-resident outlier selection (replaces the reference's CPU topk) -- */
-
-/* One call = vecquant{b}appendvecKsparse + the host glue of
- * QuantK.forward_fused_sparse (modeling_llama.py:706-751): top-thr_k largest
- * and smallest rescaled values, residual = x - lut_off[c][n-1] / lut_off[c][0],
- * zeroed where |rescaled| <= 1, sorted by channel, stored to row `col` of
- * outliers / outlier_idx (width 2*thr_k).  lut_off = lut, or the Q-Norm table.
- * Ties at the selection boundary: the lowest channel index wins. */
-int kvq_append_k_fused(int bits, int32_t *mat, const float *lut,
-                       const float *lut_off, const float *x, const float *lo,
-                       const float *hi, float *outliers, int32_t *outlier_idx,
-                       int thr_k, int H, int hd, int64_t max_len, int64_t col,
-                       void *stream);
-
-/* One call = the V top-(thr_k+1) selection of modeling_llama.py:1537-1545,
- * the per-token LUT row lut_sorted*sf+off (1086-1114), vecquant{b}appendvecVsparse
- * and the sparse row (1168-1176). lut_sorted: float [2^bits] ascending. */
-int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows,
-                       const float *lut_sorted, const float *x, float *outliers,
-                       int32_t *outlier_idx, int thr_k, int H, int hd,
-                       int64_t max_len, int64_t col, void *stream);
-
-/* Prefill counterparts for S tokens, x [H][hd][S]:
- * K: pack + rescale + outlier rows col0..col0+S-1 (modeling_llama.py:879-972);
- * needs a float workspace of H*hd*S elements for the rescaled values.
- * V: top-k, LUT rows, pack, outlier rows (modeling_llama.py:1294-1382). */
-int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut,
-                     const float *lut_off, const float *x, const float *lo,
-                     const float *hi, float *outliers, int32_t *outlier_idx,
-                     int thr_k, int H, int hd, int64_t S, int64_t max_len,
-                     int64_t col0, float *rescaled_ws, void *stream);
-int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows,
-                     const float *lut_sorted, const float *x, float *outliers,
-                     int32_t *outlier_idx, int thr_k, int H, int hd, int64_t S,
-                     int64_t max_len, int64_t col0, void *stream);
-
-/* softmax of modeling_llama.py:1972-1977 fused into one launch:
- * in: fp16 scores [H][n_cols] (optionally preceded by n_sink fp16 sink scores
- * [H][n_sink], already scaled), out: fp16 probabilities [H][n_sink+n_cols]:
- * half(score) / sqrt(hd) in fp16, softmax in fp32, rounded to fp16. */
-int kvq_softmax_f16(const uint16_t *scores, const uint16_t *sink_scores,
-                    uint16_t *probs, int H, int64_t n_cols, int n_sink,
-                    float inv_sqrt_hd, void *stream);
 
 #ifdef __cplusplus
 }

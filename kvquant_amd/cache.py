@@ -1,0 +1,346 @@
+"""QuantK / QuantV -- the cache-owning operator classes of the reference
+(ML = /root/reference/deployment/transformers/src/transformers/models/llama/
+modeling_llama.py:352-976 and 978-1385) on MI355X.
+
+Same constructor arguments, attributes (kcache/vcache, outliers,
+outlier_indices, lookup_table, klen/vlen, ...) and method signatures, so the
+reference's patched LlamaAttention and drivers (deployment/llama.py:186-198)
+work unchanged.  What changed underneath:
+  * kernels are the gfx950 HIP kernels of libkvq.so, on torch's current stream;
+  * NO host round trips: the reference copies the rescaled key / the value
+    vector to the CPU and runs torch.topk there every layer every token
+    (ML:707-714, 1812-1820); here selection stays on the GPU;
+  * LUT construction is vectorised (the reference loops 4096 times in Python,
+    ML:464-480) but evaluates the same fp16/fp32 expressions bit for bit;
+  * `device` can be chosen per instance (the reference pins everything to
+    cuda:0 with .cuda(), ML:392-397).
+There is no CPU fallback: the tensors live on a GPU and every op raises if the
+HIP library is missing.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+ZERO_CODE = {4: 7, 3: 3, 2: 1}  # KCU:2084 / 2442 / 3020
+
+
+def _threshold_k(sparsity_threshold, hidden_size):
+    return int(((1 - sparsity_threshold) / 2) * hidden_size) + 1  # ML:706
+
+
+def _default_device(device):
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("kvquant_amd.QuantK/QuantV need a GPU (there is no CPU path)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class QuantK(nn.Module):
+    """Compressed pre-RoPE key cache (ML:352-976)."""
+
+    def __init__(self, bits=2, hidden_size=4096, num_heads=32, max_position_embeddings=-1,
+                 include_sparse=False, sparsity_threshold=0.99, rope_theta=10000, use_orig_sparse=False,
+                 first_few_fp16=0, device=None):
+        super().__init__()
+        if bits not in (2, 3, 4):
+            raise ValueError("bits must be 2, 3 or 4")
+        if use_orig_sparse:
+            raise NotImplementedError("use_orig_sparse (uncapped CSR outliers) is not built yet")
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.head_dim = hidden_size // num_heads
+        self.bits = bits
+        self.lut = None
+        self.lookup_table = None
+        self.zeropoint = None
+        self.sparsity_threshold = sparsity_threshold
+        self.include_sparse = include_sparse
+        self.outlier_threshold_upper = None
+        self.outlier_threshold_lower = None
+        self.max_len = max_position_embeddings
+        self.klen = 0
+        dev = _default_device(device)
+        self.kcache = torch.zeros((num_heads, (self.head_dim // 32) * bits, self.max_len), dtype=torch.int32,
+                                  device=dev)
+        # the reference hard-codes 42 columns (ML:396); same value at 0.99 / 4096
+        self.num_outliers = 2 * _threshold_k(sparsity_threshold, hidden_size)
+        if include_sparse:
+            self.outliers = torch.zeros((self.max_len, self.num_outliers), dtype=torch.float32, device=dev)
+            self.outlier_indices = torch.zeros((self.max_len, self.num_outliers), dtype=torch.int32, device=dev)
+        self.rope_theta = rope_theta
+        self.use_orig_sparse = use_orig_sparse
+        self.first_few_fp16 = first_few_fp16
+        self.norm = False
+        self.lookup_table2 = None
+
+    @property
+    def device(self):
+        return self.kcache.device
+
+    def reset(self):
+        """ML:416-434 (plain zero fill instead of a masked assignment)."""
+        self.klen = 0
+        self.kcache.zero_()
+        if self.include_sparse:
+            self.outliers.zero_()
+            self.outlier_indices.zero_()
+
+    def load_lookup_table(self, quantizer, include_sparse=True, sparsity_threshold=0.99, norm=False):
+        """ML:437-501.  thresholds -> fp16; offset / range formed in fp16;
+        LUT row = sorted(centroids) * float(range_c) + float(offset_c) in the
+        centroid dtype, stored fp32 [H, hd, 2^bits]."""
+        dev = self.device
+        up16 = torch.as_tensor(quantizer[0]).to(dev).half().flatten()
+        lo16 = torch.as_tensor(quantizer[1]).to(dev).half().flatten()
+        lut = torch.as_tensor(quantizer[2][0]).squeeze(-1).to(dev)
+        lut, _ = lut.sort()
+        self.lut = lut
+        self.include_sparse = include_sparse
+        self.sparsity_threshold = sparsity_threshold
+        offset = (up16 + lo16) / 2
+        rangeval = (up16 - lo16) / 2
+        sf = rangeval.to(lut.dtype)
+        off = offset.to(lut.dtype)
+        n = 2 ** self.bits
+        table = lut.unsqueeze(0) * sf.unsqueeze(1) + off.unsqueeze(1)
+        self.lookup_table = table.float().reshape(self.num_heads, self.head_dim, n).contiguous()
+        self.norm = norm
+        if norm:
+            self.normscale = torch.as_tensor(quantizer[3]).to(dev)
+            self.normoffset = torch.as_tensor(quantizer[4]).to(dev)
+            t2 = (lut * self.normscale + self.normoffset).unsqueeze(0) * sf.unsqueeze(1) + off.unsqueeze(1)
+            self.lookup_table2 = t2.float().reshape(self.num_heads, self.head_dim, n).contiguous()
+        else:
+            self.normscale = self.normoffset = None
+            self.lookup_table2 = None
+        self.zeropoint = ((up16 + lo16) / 2).float()
+        self.outlier_threshold_upper = up16.float().contiguous()
+        self.outlier_threshold_lower = lo16.float().contiguous()
+
+    # -- host glue kept on the GPU ------------------------------------------------
+    def _outlier_rows(self, k_tok_major, resc_tok_major):
+        """ML:706-751 / 928-972 for [S, C] inputs; returns (vals, idx) [S, 2*thr]."""
+        n = 2 ** self.bits
+        thr = _threshold_k(self.sparsity_threshold, self.hidden_size)
+        lut = (self.lookup_table2 if self.norm else self.lookup_table).reshape(-1, n)
+        up_tmp, up_idx = torch.topk(resc_tok_major, thr, dim=-1)
+        lo_tmp, lo_idx = torch.topk(resc_tok_major, thr, dim=-1, largest=False)
+        up = torch.gather(k_tok_major, 1, up_idx) - lut[up_idx, n - 1]
+        lo = torch.gather(k_tok_major, 1, lo_idx) - lut[lo_idx, 0]
+        zeros = torch.cat((up_tmp <= 1, lo_tmp >= -1), dim=-1)
+        vals = torch.cat((up, lo), dim=-1)
+        idx = torch.cat((up_idx, lo_idx), dim=-1)
+        idx, order = idx.sort(dim=-1)
+        vals = torch.gather(vals, 1, order)
+        zeros = torch.gather(zeros, 1, order)
+        vals = vals.masked_fill(zeros, 0.0)
+        return vals, idx.int()
+
+    def forward_fused_sparse(self, q, k):
+        """ML:651-876.  q: [H, q_len, hd] post-RoPE query; k: the new pre-RoPE key
+        (C values).  Appends k and returns half [H, q_len, L] raw scores."""
+        k = k.flatten().float().contiguous()
+        q = q.float().transpose(0, 1).contiguous()
+        pos = self.klen - self.first_few_fp16
+        if self.include_sparse:
+            resc = torch.empty_like(k)
+            ops.append_k_sparse(self.bits, self.kcache, self.lookup_table, k, resc,
+                                self.outlier_threshold_lower, self.outlier_threshold_upper, pos)
+            vals, idx = self._outlier_rows(k.unsqueeze(0), resc.unsqueeze(0))
+            self.outliers[pos] = vals[0]
+            self.outlier_indices[pos] = idx[0]
+        else:
+            ops.append_k(self.bits, self.kcache, self.lookup_table, k, pos)
+        self.klen += 1
+        L = self.klen - self.first_few_fp16
+        mul = torch.empty((q.shape[0], q.shape[1], L), dtype=torch.float32, device=q.device)
+        table = self.lookup_table2 if (self.norm and self.bits == 2) else self.lookup_table  # ML:811-815
+        if self.include_sparse:
+            ops.score_k(self.bits, q, self.kcache, mul, table, L, self.rope_theta, self.first_few_fp16,
+                        self.outliers, self.outlier_indices, accumulate=False)
+        else:
+            ops.score_k(self.bits, q, self.kcache, mul, table, L, self.rope_theta, self.first_few_fp16,
+                        accumulate=False)
+        return mul.transpose(0, 1).contiguous().half()
+
+    def parallel_pack(self, k):
+        """ML:879-972.  k: [H, hd, S] pre-RoPE keys of the prompt; the cache must
+        be empty (as in the reference, which writes columns 0..S-1)."""
+        if not self.include_sparse:
+            raise AssertionError("parallel_pack needs include_sparse (as the reference, ML:975)")
+        k = k.float().contiguous()
+        S = k.shape[-1]
+        col0 = self.klen
+        self.klen += S
+        resc = torch.empty_like(k)
+        ops.pack_k_sparse_parallel(self.bits, self.kcache, self.lookup_table, k, resc,
+                                   self.outlier_threshold_lower, self.outlier_threshold_upper, col0)
+        resc_t = resc.reshape(-1, S).t().contiguous()
+        k_t = k.reshape(-1, S).t().contiguous()
+        vals, idx = self._outlier_rows(k_t, resc_t)
+        self.outliers[col0:col0 + S] = vals
+        self.outlier_indices[col0:col0 + S] = idx
+
+
+class QuantV(nn.Module):
+    """Compressed value cache with per-token codebooks (ML:978-1385)."""
+
+    def __init__(self, bits=2, hidden_size=4096, num_heads=32, max_position_embeddings=-1,
+                 include_sparse=False, sparsity_threshold=0.99, first_few_fp16=0, device=None):
+        super().__init__()
+        if bits not in (2, 3, 4):
+            raise ValueError("bits must be 2, 3 or 4")
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.head_dim = hidden_size // num_heads
+        self.bits = bits
+        self.lut = None
+        self.zeropoint = None
+        self.sparsity_threshold = sparsity_threshold
+        self.include_sparse = include_sparse
+        self.max_len = max_position_embeddings
+        dev = _default_device(device)
+        self.lookup_table = torch.zeros((self.max_len, 2 ** bits), dtype=torch.float32, device=dev)
+        self.vcache = torch.zeros((num_heads, (self.head_dim // 32) * bits, self.max_len), dtype=torch.int32,
+                                  device=dev)
+        self.vlen = 0
+        self.num_outliers = 2 * _threshold_k(sparsity_threshold, hidden_size)
+        if include_sparse:
+            self.outliers = torch.zeros((self.max_len, self.num_outliers), dtype=torch.float32, device=dev)
+            self.outlier_indices = torch.zeros((self.max_len, self.num_outliers), dtype=torch.int32, device=dev)
+        self.first_few_fp16 = first_few_fp16
+        self.norm = False
+        self.lookup_table2 = None
+
+    @property
+    def device(self):
+        return self.vcache.device
+
+    def reset(self):
+        """ML:1028-1042."""
+        self.vlen = 0
+        self.lookup_table.zero_()
+        self.vcache.zero_()
+        if self.include_sparse:
+            self.outliers.zero_()
+            self.outlier_indices.zero_()
+        if self.lookup_table2 is not None:
+            self.lookup_table2.zero_()
+
+    def load_lookup_table(self, quantizer, include_sparse=True, sparsity_threshold=0.99, norm=False):
+        """ML:1045-1066: only the sorted global centroids are kept; per-token
+        rows are built at append time."""
+        lut = torch.as_tensor(quantizer[2][0]).squeeze(-1).to(self.device).float()
+        self.lut, _ = lut.sort()
+        self.include_sparse = include_sparse
+        self.sparsity_threshold = sparsity_threshold
+        self.norm = norm
+        if norm:
+            self.normscale = torch.as_tensor(quantizer[3]).to(self.device)
+            self.normoffset = torch.as_tensor(quantizer[4]).to(self.device)
+            self.lookup_table2 = torch.zeros((self.max_len, 2 ** self.bits), dtype=torch.float32,
+                                             device=self.device)
+        else:
+            self.normscale = self.normoffset = None
+            self.lookup_table2 = None
+
+    def topk_inputs(self, v_tok_major):
+        """The four tensors the reference's attention hands over (ML:1537-1545 on the
+        CPU, 1552-1557 on the GPU): topk(thr+1) of each token's values, both sides.
+        Here always on the GPU."""
+        k = _threshold_k(self.sparsity_threshold, self.hidden_size) + 1
+        uv, ui = torch.topk(v_tok_major, k, dim=-1)
+        lv, li = torch.topk(v_tok_major, k, dim=-1, largest=False)
+        return uv, ui, lv, li
+
+    def forward_fused_sparse(self, score, v, upper_outlier_vals=None, upper_outlier_indices=None,
+                             lower_outlier_vals=None, lower_outlier_indices=None):
+        """ML:1069-1291.  score: [H, q_len, L+1] probabilities; v: the new value
+        (C values).  With include_sparse the four top-(thr+1) tensors may be passed as
+        in the reference or left None to be computed here on the GPU."""
+        score = score.float()
+        v_in = v.flatten()
+        v = v_in.float().contiguous()
+        pos = self.vlen - self.first_few_fp16
+        zc = ZERO_CODE[self.bits]
+        if self.include_sparse:
+            if upper_outlier_vals is None:
+                uv, ui, lv, li = self.topk_inputs(v.unsqueeze(0))
+                upper_outlier_vals, upper_outlier_indices = uv[0], ui[0]
+                lower_outlier_vals, lower_outlier_indices = lv[0], li[0]
+            dev = v.device
+            upper_outlier_vals = upper_outlier_vals.to(dev)
+            lower_outlier_vals = lower_outlier_vals.to(dev)
+            maxval = upper_outlier_vals[-1]
+            minval = lower_outlier_vals[-1]
+            uv, lv = upper_outlier_vals[:-1], lower_outlier_vals[:-1]
+            ui, li = upper_outlier_indices[:-1].to(dev), lower_outlier_indices[:-1].to(dev)
+            offset = (maxval + minval) / 2
+            sf = (maxval - minval) / 2
+        else:
+            # compute_lut (ML:318-349) on the un-widened vector: fp16 arithmetic for an fp16 v
+            maxval, minval = v_in.max(), v_in.min()
+            offset = (maxval + minval) / 2
+            sf = (maxval - minval) / 2
+        # ML:1113: lut * sf.item() + offset.item() in fp32, kept on the GPU (no .item() sync)
+        row = self.lut.float() * sf.float() + offset.float()
+        self.lookup_table[pos] = row
+        if self.norm:
+            self.lookup_table2[pos] = (self.lut.float() * self.normscale + self.normoffset) * sf.float() + offset.float()
+        score = score.transpose(0, 1).contiguous()
+        if self.include_sparse:
+            zp_row = self.lookup_table2[pos] if (self.norm and self.bits == 2) else row   # ML:1153-1156
+            zeropoint = zp_row[zc]
+            ops.append_v_sparse(self.bits, self.vcache, self.lookup_table, v, float(minval), float(maxval), pos)
+            vals = torch.cat((uv, lv), dim=-1) - zeropoint
+            idx = torch.cat((ui, li), dim=-1)
+            idx, order = idx.sort()
+            self.outliers[pos] = vals[order]
+            self.outlier_indices[pos] = idx.int()
+        else:
+            ops.append_v(self.bits, self.vcache, self.lookup_table, v, pos)
+        self.vlen += 1
+        L = self.vlen - self.first_few_fp16
+        mul = torch.empty((score.shape[0], score.shape[1], self.head_dim), dtype=torch.float32,
+                          device=score.device)
+        table = self.lookup_table2 if (self.norm and self.bits == 2) else self.lookup_table      # ML:1237-1240
+        if self.include_sparse:
+            ops.mix_v(self.bits, score, self.vcache, mul, table, L, self.outliers, self.outlier_indices,
+                      accumulate=False)
+        else:
+            ops.mix_v(self.bits, score, self.vcache, mul, table, L, accumulate=False)
+        return mul.transpose(0, 1).contiguous().half()
+
+    def parallel_pack(self, v, upper_outlier_vals=None, upper_outlier_indices=None,
+                      lower_outlier_vals=None, lower_outlier_indices=None):
+        """ML:1294-1382.  v: [H, hd, S]; top-k tensors [S, thr+1] or None (computed
+        here on the GPU)."""
+        if not self.include_sparse:
+            raise AssertionError("parallel_pack needs include_sparse (as the reference, ML:1322)")
+        v = v.float().contiguous()
+        S = v.shape[-1]
+        col0 = self.vlen
+        self.vlen += S
+        if upper_outlier_vals is None:
+            vt = v.reshape(-1, S).t().contiguous()
+            upper_outlier_vals, upper_outlier_indices, lower_outlier_vals, lower_outlier_indices = \
+                self.topk_inputs(vt)
+        maxval = upper_outlier_vals[:, -1].float().contiguous()
+        minval = lower_outlier_vals[:, -1].float().contiguous()
+        uv, lv = upper_outlier_vals[:, :-1], lower_outlier_vals[:, :-1]
+        ui, li = upper_outlier_indices[:, :-1], lower_outlier_indices[:, :-1]
+        offset = (maxval + minval) / 2
+        sf = (maxval - minval) / 2
+        rows = self.lut.float().unsqueeze(0) * sf.unsqueeze(-1) + offset.unsqueeze(-1)
+        self.lookup_table[col0:col0 + S] = rows
+        ops.pack_v_sparse_parallel(self.bits, self.vcache, self.lookup_table, v, minval, maxval, col0)
+        zc = ZERO_CODE[self.bits]
+        zp_src = self.lookup_table2 if self.norm else self.lookup_table
+        vals = torch.cat((uv, lv), dim=-1) - zp_src[col0:col0 + S, zc].unsqueeze(-1)
+        idx = torch.cat((ui, li), dim=-1)
+        idx, order = idx.sort(dim=-1)
+        vals = torch.gather(vals, 1, order)
+        self.outliers[col0:col0 + S] = vals
+        self.outlier_indices[col0:col0 + S] = idx.int()

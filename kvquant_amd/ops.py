@@ -1,0 +1,159 @@
+"""Typed wrappers over the C ABI of libkvq.so (include/kvq.h): torch tensors in,
+raw device pointers + torch's current stream out.  Argument checks raise
+ValueError; a failing library call raises KvqError.  No CPU path."""
+import torch
+
+from . import _lib
+
+_ws = {}  # device index -> workspace tensor for the V matvec partial sums
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if not torch.is_tensor(t):
+        raise ValueError("%s: expected a tensor" % name)
+    if not t.is_cuda:
+        raise ValueError("%s: expected a GPU tensor (got %s); kvquant_amd has no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise ValueError("%s: expected dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s: expected a contiguous tensor" % name)
+    return t.data_ptr()
+
+
+def _f(t, name):
+    return _chk(t, torch.float32, name)
+
+
+def _i(t, name):
+    return _chk(t, torch.int32, name)
+
+
+def _cache_dims(mat, bits):
+    if mat.dim() != 3:
+        raise ValueError("mat: expected [num_heads, head_dim/32*bits, max_len]")
+    H, W, max_len = mat.shape
+    if W % bits:
+        raise ValueError("mat.shape[1]=%d is not a multiple of bits=%d" % (W, bits))
+    return H, W // bits * 32, max_len
+
+
+def _workspace(device, nbytes):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w
+
+
+class _Dev:
+    """device guard equivalent to the reference's OptionalCUDAGuard"""
+
+    def __init__(self, t):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None and self.idx != torch.cuda.current_device():
+            self.prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+
+
+def _L():
+    return _lib.lib()
+
+
+def append_k(bits, mat, lut, x, col):
+    H, hd, max_len = _cache_dims(mat, bits)
+    with _Dev(mat):
+        _lib.check(_L().kvq_append_k(bits, _i(mat, "mat"), _f(lut, "lookup_table"), _f(x, "newvec"), H, hd,
+                                     max_len, int(col), _stream()), "kvq_append_k")
+
+
+def append_v(bits, mat, lut_rows, x, col):
+    H, hd, max_len = _cache_dims(mat, bits)
+    with _Dev(mat):
+        _lib.check(_L().kvq_append_v(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"), _f(x, "newvec"), H, hd,
+                                     max_len, int(col), _stream()), "kvq_append_v")
+
+
+def append_k_sparse(bits, mat, lut, x, rescaled, lo, hi, col):
+    H, hd, max_len = _cache_dims(mat, bits)
+    with _Dev(mat):
+        _lib.check(_L().kvq_append_k_sparse(bits, _i(mat, "mat"), _f(lut, "lookup_table"), _f(x, "newvec"),
+                                            _f(rescaled, "outliers_rescaled"), _f(lo, "lower"), _f(hi, "upper"),
+                                            H, hd, max_len, int(col), _stream()), "kvq_append_k_sparse")
+
+
+def append_v_sparse(bits, mat, lut_rows, x, lo, hi, col):
+    H, hd, max_len = _cache_dims(mat, bits)
+    with _Dev(mat):
+        _lib.check(_L().kvq_append_v_sparse(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"), _f(x, "newvec"),
+                                            float(lo), float(hi), H, hd, max_len, int(col), _stream()),
+                   "kvq_append_v_sparse")
+
+
+def pack_k_sparse_parallel(bits, mat, lut, x, rescaled, lo, hi, col0=0):
+    H, hd, max_len = _cache_dims(mat, bits)
+    S = x.shape[-1]
+    with _Dev(mat):
+        _lib.check(_L().kvq_pack_k_sparse_parallel(bits, _i(mat, "mat"), _f(lut, "lookup_table"), _f(x, "newvec"),
+                                                   _f(rescaled, "outliers_rescaled"), _f(lo, "lower"),
+                                                   _f(hi, "upper"), H, hd, S, max_len, int(col0), _stream()),
+                   "kvq_pack_k_sparse_parallel")
+
+
+def pack_v_sparse_parallel(bits, mat, lut_rows, x, lo, hi, col0=0):
+    H, hd, max_len = _cache_dims(mat, bits)
+    S = x.shape[-1]
+    with _Dev(mat):
+        _lib.check(_L().kvq_pack_v_sparse_parallel(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"),
+                                                   _f(x, "newvec"), _f(lo, "lower"), _f(hi, "upper"), H, hd, S,
+                                                   max_len, int(col0), _stream()), "kvq_pack_v_sparse_parallel")
+
+
+def score_k(bits, q, mat, mul, lut, L, theta, pos_offset, outliers=None, outlier_indices=None,
+            accumulate=True):
+    """q [q_len,H,128] f32, mul [q_len,H,L] f32 (in place)."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    if q.dim() != 3 or mul.dim() != 3 or q.shape[0] != mul.shape[0]:
+        raise ValueError("vec must be [q_len, H, head_dim] and mul [q_len, H, kcachelen]")
+    if mul.shape[2] != L:
+        raise ValueError("mul.shape[2] must equal kcachelen")
+    n_out = 0 if outliers is None else outliers.shape[1]
+    with _Dev(q):
+        _lib.check(_L().kvq_score_k(
+            bits, _f(q, "vec"), _i(mat, "mat"), _f(mul, "mul"), _f(lut, "lookup_table"), q.shape[0], H, hd,
+            int(L), max_len, float(theta), int(pos_offset),
+            None if outliers is None else _f(outliers, "outliers"),
+            None if outliers is None else _i(outlier_indices, "outlier_indices"), n_out,
+            1 if accumulate else 0, _stream()), "kvq_score_k")
+
+
+def mix_v(bits, p, mat, mul, lut_rows, L, outliers=None, outlier_indices=None, accumulate=True):
+    """p [q_len,H,L] f32, mul [q_len,H,128] f32 (in place)."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    if p.dim() != 3 or mul.dim() != 3 or p.shape[0] != mul.shape[0]:
+        raise ValueError("vec must be [q_len, H, vcachelen] and mul [q_len, H, head_dim]")
+    if p.shape[2] != L:
+        raise ValueError("vec.shape[2] must equal vcachelen")
+    q_len = p.shape[0]
+    n_out = 0 if outliers is None else outliers.shape[1]
+    with _Dev(p):
+        nbytes = _L().kvq_mix_v_workspace_bytes(bits, q_len, H, hd, int(L))
+        ws = _workspace(p.device, nbytes)
+        _lib.check(_L().kvq_mix_v(
+            bits, _f(p, "vec"), _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), q_len, H, hd,
+            int(L), max_len, None if outliers is None else _f(outliers, "outliers"),
+            None if outliers is None else _i(outlier_indices, "outlier_indices"), n_out,
+            1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "kvq_mix_v")
