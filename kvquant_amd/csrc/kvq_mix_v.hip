@@ -3,244 +3,442 @@
 // KCU:3211-3433 (+4117-4491, 4998-5248), SPMV_ATOMIC_BALANCED KCU:437-470,
 // launchers KCU:3491-3538, 3625-3690.
 //
-// CDNA4 design.  The reduction runs over tokens, so (unlike the reference, which
-// puts a token on every thread and transposes 32 KB of products through LDS per
-// block, then issues 128 atomics) a LANE OWNS A ROW UNIT of the cache -- one
-// packed word-row of one head (8 / 16 channels for 4 / 2 bit, three rows = 32
-// channels for 3 bit) -- and walks the token axis, which is the contiguous
-// axis of that row: 16-byte loads, 64 B of a row per batch.  The 8..32 channel
-// sums of a unit live in VGPRs for the whole token range: no cross-lane
-// reduction, no transposes, no atomics.  All lanes of a wave decode the SAME
-// token at the same time, so the per-token codebook row (64 B) is one
-// conflict-free broadcast LDS read per code; rows are staged per 64-token chunk.
-// A workgroup = 4 waves = 4 unit blocks (256 units) over one token range; every
-// workgroup writes one slab of partial sums and a second tiny kernel adds the
-// slabs into `mul` in a fixed order (deterministic, unlike atomics).
-// The sparse residuals are handled by extra workgroups of the same launch that
-// accumulate val*p into an LDS copy of the output vector (ds_add_f32).
+// CDNA4 design.  The reduction runs over tokens, and the cache is laid out
+// [row][token] with the token axis contiguous.  The reference puts a token on
+// every thread, transposes 32 KB of products through LDS per block and issues
+// 128 atomics per block.  Here:
+//   * HBM side: the packed rows are streamed with LDS-DMA (global_load_lds, 16 B
+//     per lane): every wave instruction moves whole 64/128-byte row segments
+//     straight into an LDS tile, no VGPR staging, one chunk ahead of the math
+//     (double buffered, one barrier per chunk);
+//   * LDS side: a LANE OWNS A ROW UNIT (one packed word-row = 8 / 16 channels for
+//     4 / 2 bit, three rows = 32 channels for 3 bit) and reads its own row back
+//     with ds_read_b128.  The tile is stored with the 16-byte quads of row r
+//     rotated by f(r) (done on the DMA's per-lane SOURCE address, the LDS image
+//     of a DMA instruction is linear by construction) so those reads are
+//     bank-conflict free;
+//   * all lanes of a wave decode the SAME token at the same time, so the
+//     per-token codebook row is a broadcast, conflict-free ds_read_b32 per code
+//     (2 address ops + 1 FMA per code), and the 8..32 channel sums of a unit
+//     stay in VGPRs for the whole token range: no cross-lane reduction, no
+//     transposes, no atomics;
+//   * a workgroup = 512 lanes = UW units x SLOTS token slots over one token
+//     range; slots are summed through LDS once at the end and every workgroup
+//     writes its channel slice of one partial slab; a second small kernel adds
+//     the slabs into `mul` in a fixed order (deterministic);
+//   * the sparse residuals of the range are scattered into an LDS accumulator
+//     (ds_add_f32) by the same workgroup while its first DMA chunk is in flight.
+// Needs max_len % 4 == 0 (16-byte DMA source alignment); other shapes take the
+// row-per-lane fallback in kvq_mix_v_rows.h.
 // Algorithmic HBM bytes per cached token: C*bits/8 + 4*2^bits (codebook row)
 // + 4*H (probabilities) (+ 8*n_out sparse).
 #include "kvq_common.h"
 #include "kvq_host.h"
+#include "kvq_mix_v_rows.h"
+
+#include <cstdlib>
 
 namespace kvq {
 
-constexpr int kChunk = 64;     // tokens per staged codebook chunk
-constexpr int kMixWaves = 4;
-constexpr int kSparseTokens = 2048;  // tokens per sparse workgroup
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+
+// LDS-DMA issued from inline asm so that hipcc does not put it on its own vmcnt scoreboard (with the
+// builtin it waits vmcnt(0) in front of every later ds_read and the copy never overlaps the math;
+// cdna_hip_programming.md 5.7).  lds_dst: wave-uniform LDS byte address (goes to M0), gsrc: per-lane
+// source.  Completion is waited for explicitly (dma_wait_all) before the barrier that publishes a stage.
+__device__ __forceinline__ void dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;   // source = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(const lds_byte_t *)p;
+}
 
 template <int BITS>
-struct Unit {
-  static constexpr int kWords = BITS == 3 ? 3 : 1;                   // word-rows per unit
-  static constexpr int kCh = BITS == 4 ? 8 : (BITS == 3 ? 32 : 16);  // channels per unit
-  static constexpr int kPerHead = kHeadDim / kCh;
-  static constexpr int kBatch = BITS == 3 ? 8 : 16;  // tokens per register batch (16-byte loads)
+struct VCfg {
+  static constexpr int N = Fmt<BITS>::kN;
+  static constexpr int WORDS = Unit<BITS>::kWords;     // word-rows per unit
+  static constexpr int CH = Unit<BITS>::kCh;           // channels per unit
+  static constexpr int UPH = kHeadDim / CH;            // units per head
+  static constexpr int NT = 512;                       // threads per workgroup
+  static constexpr int UW = BITS == 3 ? 128 : 256;     // units per workgroup
+  static constexpr int SLOTS = NT / UW;                // token slots
+  static constexpr int CT = BITS == 3 ? 16 : 32;       // tokens per chunk
+  static constexpr int QR = CT / 4;                    // 16-byte quads per tile row
+  static constexpr int SH = CT == 32 ? 1 : 2;          // log2(tile rows per 256 B)
+  static constexpr int ROWS = UW * WORDS;              // tile rows
+  static constexpr int ROWB = CT * 4;                  // tile row bytes
+  static constexpr int TILE_B = ROWS * ROWB;
+  static constexpr int HW = UW / UPH;                  // heads per workgroup
+  static constexpr int LUT_B = CT * N * 4;
+  static constexpr int P_B = HW * CT * 4;
+  static constexpr int QPL = QR / SLOTS;               // quads per lane per chunk
+  static constexpr int BUF_B = TILE_B + LUT_B + P_B;   // one pipeline stage
+  static constexpr int SACC_B = UW * CH * 4;           // sparse accumulator
+  static constexpr int RED_B = NT * CH * 4;            // slot reduction (aliases the stages)
+  static constexpr int SMEM_B = (2 * BUF_B > RED_B ? 2 * BUF_B : RED_B) + SACC_B;
+  static_assert(QR % SLOTS == 0, "slots must split the chunk's quads");
 };
 
-typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-
-struct MixVArgs {
+struct MixArgs {
   const float *p;          // [q_len][H][L]
   const uint32_t *mat;     // [rows][max_len]
   const float *lut_rows;   // [max_len][N]
   const float *outliers;
   const int32_t *idx;
-  float *partial;          // [slabs][q_len][C]
+  float *partial;          // [n_ranges][q_len][C]
   int H;
   int q_len;
   int64_t L;
   int64_t max_len;
-  int64_t tr;              // tokens per dense range (multiple of kChunk)
-  int n_ranges;
-  int ubg;                 // unit-block groups (workgroups per range)
+  int64_t tr;              // tokens per range (multiple of CT)
+  int groups;              // unit groups (workgroups per range)
   int n_units;
   int n_out;
+  int dbg;                 // development only: 1 = skip math, 2 = skip DMA
 };
 
-template <int BITS, int I, int WORDS>
-__device__ __forceinline__ unsigned unit_code(const uint32_t (&w)[WORDS]) {
-  if constexpr (BITS == 3) {
-    return code_of<3, I>(w);
-  } else if constexpr (BITS == 4) {
-    return (w[0] >> (4 * I)) & 0xfu;
-  } else {
-    return (w[0] >> (2 * I)) & 0x3u;
+// Per-lane constants of the chunk DMA.  Every tile DMA instruction of a wave moves 64/QR consecutive
+// tile rows; instruction k of a wave is rows 64/QR*8*k further down, which is a wave-uniform pointer
+// increment, so ONE 32-bit lane offset serves all of a wave's tile instructions.
+struct DmaLane {
+  uint32_t tile_row;   // first tile row of this lane (instruction k adds k * rows_per_round)
+  uint32_t tile_q4;    // token offset (4*source quad) inside the chunk
+  uint32_t lut_tok;    // token (within chunk) whose codebook row this lane fetches
+  uint32_t lut_sub;    // float offset inside that row
+  uint32_t p_head;     // head (relative to h0) / token (within chunk) of the probability this lane fetches
+  uint32_t p_tok;
+};
+
+template <int BITS>
+__device__ __forceinline__ DmaLane make_dma_lane() {
+  using Cfg = VCfg<BITS>;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  DmaLane d;
+  const int s = wave * 64 + lane;              // slot of the wave's first tile instruction
+  const int r = s / Cfg::QR;
+  const int pos = s % Cfg::QR;
+  d.tile_row = r;
+  d.tile_q4 = 4 * ((pos - ((r >> Cfg::SH) & (Cfg::QR - 1))) & (Cfg::QR - 1));
+  // codebook rows: LDS row index pidx holds token tl with pidx = (qq*4+e)*SLOTS + slot,
+  // tl = (slot*QPL+qq)*4+e: the rows the slots decode in one step sit next to each other
+  const int pidx = (s * 4) / Cfg::N;
+  const int qe = pidx / Cfg::SLOTS, slp = pidx % Cfg::SLOTS;
+  d.lut_tok = (slp * Cfg::QPL + qe / 4) * 4 + qe % 4;
+  d.lut_sub = (s * 4) % Cfg::N;
+  d.p_head = s / Cfg::CT;
+  d.p_tok = s % Cfg::CT;
+  return d;
+}
+
+// issue the DMA of one chunk (tokens [c0, c0+CT)) into stage `buf`
+template <int BITS>
+__device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, uint32_t buf, int64_t c0,
+                                            int row_base, int n_rows_valid, int h0, int b) {
+  using Cfg = VCfg<BITS>;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int NW = Cfg::NT / 64;
+  constexpr int RPI = 64 / Cfg::QR;                  // tile rows per DMA instruction
+  constexpr int N_TILE = Cfg::TILE_B / 1024;
+  constexpr int K_TILE = (N_TILE + NW - 1) / NW;     // tile instructions per wave
+  constexpr int LUT_SLOTS = Cfg::LUT_B / 16;
+  constexpr int N_P = Cfg::P_B / 256;
+  constexpr int K_P = (N_P + NW - 1) / NW;
+  // ---- packed rows: uniform base per instruction, ONE 32-bit lane offset (bytes) for all of them
+  {
+    int64_t tok = c0 + d.tile_q4;
+    if (tok + 4 > a.max_len) tok = a.max_len - 4;
+    const uint32_t *gbase = a.mat + (int64_t)row_base * a.max_len + c0;
+    const uint32_t toff = (uint32_t)(tok - c0);
+#pragma unroll
+    for (int k = 0; k < K_TILE; k++) {
+      const int j = wave + k * NW;
+      if (j < N_TILE) {
+        int r = d.tile_row + k * NW * RPI;
+        if (r >= n_rows_valid) r = n_rows_valid - 1;
+        const uint32_t voff = ((uint32_t)r * (uint32_t)a.max_len + toff) * 4u;   // < 2^32 (checked by the host)
+        dma16(gbase, voff, buf + j * 1024);
+      }
+    }
+  }
+  // ---- codebook rows of the chunk
+  if ((int)threadIdx.x < LUT_SLOTS) {   // wave-granular: LUT_SLOTS is a multiple of 64 or < 64
+    int64_t t = c0 + d.lut_tok;
+    if (t >= a.max_len) t = a.max_len - 1;
+    const float *gbase = a.lut_rows + c0 * Cfg::N;
+    const uint32_t voff = ((uint32_t)(t - c0) * Cfg::N + d.lut_sub) * 4u;
+    dma16(gbase, voff, buf + Cfg::TILE_B + wave * 1024);
+  }
+  // ---- probabilities of the workgroup's heads, 4 B per lane
+  {
+    const float *gbase = a.p + ((int64_t)b * a.H + h0) * a.L + c0;
+    int64_t t = c0 + d.p_tok;
+    if (t >= a.L) t = a.L - 1;
+    const uint32_t toff = (uint32_t)(t - c0);
+#pragma unroll
+    for (int k = 0; k < K_P; k++) {
+      const int j = wave + k * NW;
+      if (j < N_P) {
+        int hr = d.p_head + k * NW * (64 / Cfg::CT);
+        if (h0 + hr >= a.H) hr = a.H - 1 - h0;
+        const uint32_t voff = ((uint32_t)hr * (uint32_t)a.L + toff) * 4u;
+        dma4(gbase, voff, buf + Cfg::TILE_B + Cfg::LUT_B + j * 256);
+      }
+    }
   }
 }
 
+template <int BITS, int I, int WORDS>
+__device__ __forceinline__ unsigned vcode(const uint32_t (&w)[WORDS]) {
+  if constexpr (BITS == 3) return code_of<3, I>(w);
+  else if constexpr (BITS == 4) return (w[0] >> (4 * I)) & 0xfu;
+  else return (w[0] >> (2 * I)) & 0x3u;
+}
+
 template <int BITS>
-__global__ __launch_bounds__(kMixWaves * 64) void mix_v_kernel(MixVArgs a) {
-  constexpr int N = Fmt<BITS>::kN;
-  constexpr int WORDS = Unit<BITS>::kWords;
-  constexpr int CH = Unit<BITS>::kCh;
-  constexpr int NT = kMixWaves * 64;
-  constexpr int kBatch = Unit<BITS>::kBatch;
-  const int C = a.H * kHeadDim;
+__global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
+  using Cfg = VCfg<BITS>;
+  constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B];  // static: LDS offsets fold into ds immediates
+  unsigned char *stage0 = smem;
+  float *sacc = reinterpret_cast<float *>(smem + (Cfg::SMEM_B - Cfg::SACC_B));
+
+  const int tid = threadIdx.x;
+  const int ul = tid % Cfg::UW;          // unit within the workgroup
+  const int sl = tid / Cfg::UW;          // token slot (wave-uniform)
+  const int g = blockIdx.x % a.groups;
+  const int range = blockIdx.x / a.groups;
   const int b = blockIdx.z;
-  const int n_dense = a.n_ranges * a.ubg;
+  const int C = a.H * kHeadDim;
+  const int u0 = g * Cfg::UW;
+  const int row_base = u0 * WORDS;
+  int n_units_valid = a.n_units - u0;
+  if (n_units_valid > Cfg::UW) n_units_valid = Cfg::UW;
+  const int n_rows_valid = n_units_valid * WORDS;
+  const int h0 = u0 / Cfg::UPH;
+  const int hl = ul / Cfg::UPH;
+  const int64_t t0 = (int64_t)range * a.tr;
+  const int64_t t1 = (t0 + a.tr < a.L) ? (t0 + a.tr) : a.L;
+  const int n_chunks = (int)((t1 - t0 + CT - 1) / CT);
 
-  __shared__ __attribute__((aligned(16))) float lds[4096];  // 16 KB: codebook chunks / sparse accumulator
+  const DmaLane dl = make_dma_lane<BITS>();
+  const uint32_t lds0 = lds_addr(smem);
+  issue_chunk<BITS>(a, dl, lds0, t0, row_base, n_rows_valid, h0, b);
 
-  if ((int)blockIdx.x >= n_dense) {
-    // ---------------- sparse residual workgroup -------------------------------
-    const int s = blockIdx.x - n_dense;
-    float *slab = a.partial + ((int64_t)(a.n_ranges * a.ubg + s) * a.q_len + b) * C;
-    // reference: the sparse part only sees batch 0 (KCU:3675)
-    const bool active = (b == 0) && a.outliers != nullptr;
-    for (int c0 = 0; c0 < C; c0 += 4096) {
-      const int cn = (C - c0 < 4096) ? (C - c0) : 4096;
-      for (int i = threadIdx.x; i < cn; i += NT) lds[i] = 0.f;
-      __syncthreads();
-      if (active) {
-        const int64_t t0 = (int64_t)s * kSparseTokens;
-        const int64_t t1 = (t0 + kSparseTokens < a.L) ? (t0 + kSparseTokens) : a.L;
-        const int64_t e0 = t0 * a.n_out, e1 = t1 * a.n_out;
-        for (int64_t e = e0 + threadIdx.x; e < e1; e += NT) {
-          const float val = a.outliers[e];
-          const int row = a.idx[e];
-          if (row < c0 || row >= c0 + cn) continue;
-          const int64_t t = e / a.n_out;
-          const float pt = a.p[(int64_t)(row >> 7) * a.L + t];
-          atomicAdd(&lds[row - c0], val * pt);
-        }
-      }
-      __syncthreads();
-      for (int i = threadIdx.x; i < cn; i += NT) slab[c0 + i] = lds[i];
-      __syncthreads();
-    }
-    return;
+  // ---- sparse residuals of this token range that fall in this group's channels
+  const bool sparse = (a.outliers != nullptr) && (b == 0);   // reference: batch 0 only (KCU:3675)
+  if (a.outliers != nullptr) {
+    for (int i = tid; i < Cfg::UW * CH; i += Cfg::NT) sacc[i] = 0.f;
   }
-
-  // ---------------- dense workgroup ---------------------------------------------
-  const int range = blockIdx.x / a.ubg;
-  const int ub = (blockIdx.x % a.ubg) * kMixWaves + (threadIdx.x >> 6);
-  const int u = ub * 64 + (threadIdx.x & 63);
-  const bool uvalid = u < a.n_units;
-  const int uc = uvalid ? u : a.n_units - 1;
-  const int h = uc / Unit<BITS>::kPerHead;
-  const int64_t t_begin = (int64_t)range * a.tr;
-  const int64_t t_end = (t_begin + a.tr < a.L) ? (t_begin + a.tr) : a.L;
-  const uint32_t *rowp = a.mat + (int64_t)uc * WORDS * a.max_len;
-  const float *ph = a.p + ((int64_t)b * a.H + h) * a.L;
+  __syncthreads();
+  if (sparse) {
+    const int ch0 = u0 * CH;
+    const float *ov = a.outliers + t0 * a.n_out;
+    const int32_t *oi = a.idx + t0 * a.n_out;
+    const float *p0 = a.p + t0;
+    const unsigned nent = (unsigned)(t1 - t0) * (unsigned)a.n_out;   // < 2^31: 32-bit index math
+    for (unsigned e = tid; e < nent; e += Cfg::NT) {
+      const int row = oi[e];
+      const unsigned rel = (unsigned)(row - ch0);
+      if (rel < (unsigned)(Cfg::UW * CH)) {
+        const float val = ov[e];
+        const unsigned tl = e / (unsigned)a.n_out;
+        const float pt = p0[(int64_t)(row >> 7) * a.L + tl];
+        atomicAdd(&sacc[rel], val * pt);
+      }
+    }
+  }
 
   float acc[CH];
 #pragma unroll
   for (int i = 0; i < CH; i++) acc[i] = 0.f;
 
-  for (int64_t c0 = t_begin; c0 < t_end; c0 += kChunk) {
-    // stage the chunk's codebook rows: lds[tl*N + v]
-    __syncthreads();
-    for (int i = threadIdx.x; i < kChunk * N / 4; i += NT) {
-      int64_t tok = c0 + (i * 4) / N;
-      if (tok >= a.L) tok = a.L - 1;
-      const float4 r = *reinterpret_cast<const float4 *>(a.lut_rows + tok * N + (i * 4) % N);
-      *reinterpret_cast<float4 *>(&lds[i * 4]) = r;
+  // per-lane constant pieces of the LDS addresses
+  int rowoff[WORDS], rot[WORDS];
+#pragma unroll
+  for (int wi = 0; wi < WORDS; wi++) {
+    const int r = ul * WORDS + wi;
+    rowoff[wi] = r * Cfg::ROWB;
+    rot[wi] = (r >> Cfg::SH) & (Cfg::QR - 1);
+  }
+
+  // slot pattern OR-ed into the pre-masked nibble bytes (4-bit fast path): byte = slot*64 + code*4
+  const uint32_t slotpat = (uint32_t)sl * 0x40404040u;
+
+  auto chunk = [&](auto STAGE, int ci) {
+    constexpr int stage = decltype(STAGE)::value;
+    const int64_t c0 = t0 + (int64_t)ci * CT;
+    dma_wait_all();                       // this wave's DMA pieces of chunk ci have landed
+    __syncthreads();                      // ... and everybody else's; the other stage is free again
+    if (ci + 1 < n_chunks && !(a.dbg & 2))
+      issue_chunk<BITS>(a, dl, lds0 + (1 - stage) * Cfg::BUF_B, c0 + CT, row_base, n_rows_valid, h0, b);
+    const unsigned char *tile = smem + stage * Cfg::BUF_B;
+    const unsigned char *lutb = smem + stage * Cfg::BUF_B + Cfg::TILE_B;
+    float *pb = reinterpret_cast<float *>(smem + stage * Cfg::BUF_B + Cfg::TILE_B + Cfg::LUT_B);
+    const int rem = (int)(t1 - c0);       // tokens of this range left in the chunk
+    if (rem < CT) {                       // ragged last chunk: zero the probabilities past the end once
+      for (int i = tid; i < Cfg::HW * CT; i += Cfg::NT)
+        if (i % CT >= rem) pb[i] = 0.f;
+      __syncthreads();
     }
-    __syncthreads();
-#pragma unroll 1
-    for (int bt = 0; bt < kChunk / kBatch; bt++) {
-      const int64_t tb = c0 + bt * kBatch;
-      if (tb >= t_end) break;
-      u32x4_u wv[WORDS][kBatch / 4];
-      f32x4_u pv[kBatch / 4];
-      if (tb + kBatch <= t_end) {
+    if (a.dbg & 1) return;
+    int rotv[WORDS];
 #pragma unroll
-        for (int j = 0; j < kBatch / 4; j++) {
+    for (int wi = 0; wi < WORDS; wi++) {
+      rotv[wi] = rot[wi];
+      asm volatile("" : "+v"(rotv[wi]));   // recompute the tile addresses per chunk (else hoisted and spilled)
+    }
+    static_for<0, Cfg::QPL>([&](auto QQ) {
+      constexpr int qq = decltype(QQ)::value;
+      const int q = sl * Cfg::QPL + qq;
+      uint4 wq[WORDS];
 #pragma unroll
-          for (int wi = 0; wi < WORDS; wi++)
-            wv[wi][j] = *reinterpret_cast<const u32x4_u *>(rowp + (int64_t)wi * a.max_len + tb + j * 4);
-          pv[j] = *reinterpret_cast<const f32x4_u *>(ph + tb + j * 4);
-        }
-      } else {  // ragged tail: clamp the address, zero the probability
-#pragma unroll
-        for (int j = 0; j < kBatch / 4; j++) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const int64_t tt = tb + j * 4 + e;
-            const int64_t tc = tt < t_end ? tt : t_end - 1;
-#pragma unroll
-            for (int wi = 0; wi < WORDS; wi++) wv[wi][j][e] = rowp[(int64_t)wi * a.max_len + tc];
-            pv[j][e] = tt < t_end ? ph[tc] : 0.f;
-          }
-        }
-      }
-      const float *tabb = lds + bt * kBatch * N;
-#pragma unroll
-      for (int tt = 0; tt < kBatch; tt++) {
+      for (int wi = 0; wi < WORDS; wi++)
+        wq[wi] = *reinterpret_cast<const uint4 *>(tile + rowoff[wi] + (((q + rotv[wi]) & (Cfg::QR - 1)) << 4));
+      const float4 p4 = *reinterpret_cast<const float4 *>(pb + hl * CT + q * 4);
+      static_for<0, 4>([&](auto E) {
+        constexpr int e = decltype(E)::value;
         uint32_t w[WORDS];
 #pragma unroll
-        for (int wi = 0; wi < WORDS; wi++) w[wi] = wv[wi][tt / 4][tt % 4];
-        const float pt = pv[tt / 4][tt % 4];
-        const float *tab = tabb + tt * N;
-        static_for<0, CH>([&](auto I) {
-          constexpr int i = decltype(I)::value;
-          acc[i] = fmaf(tab[unit_code<BITS, i, WORDS>(w)], pt, acc[i]);
-        });
-      }
-    }
+        for (int wi = 0; wi < WORDS; wi++)
+          w[wi] = e == 0 ? wq[wi].x : (e == 1 ? wq[wi].y : (e == 2 ? wq[wi].z : wq[wi].w));
+        const float pt = e == 0 ? p4.x : (e == 1 ? p4.y : (e == 2 ? p4.z : p4.w));
+        if constexpr (BITS == 4) {
+          // even / odd nibbles as bytes holding code*4 (+ slot*64): one v_bfe_u32 per code gives the
+          // complete variable part of the LDS address, everything else is an instruction immediate
+          const uint32_t we = ((w[0] << 2) & 0x3C3C3C3Cu) | slotpat;
+          const uint32_t wo = ((w[0] >> 2) & 0x3C3C3C3Cu) | slotpat;
+          const unsigned char *row = lutb + (qq * 4 + e) * Cfg::SLOTS * N * 4;
+          static_for<0, 8>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const uint32_t src = (i & 1) ? wo : we;
+            const uint32_t off = (src >> (8 * (i / 2))) & 0xffu;
+            acc[i] = fmaf(*reinterpret_cast<const float *>(row + off), pt, acc[i]);
+          });
+        } else {
+          const float *tab = reinterpret_cast<const float *>(lutb) + ((qq * 4 + e) * Cfg::SLOTS + sl) * N;
+          static_for<0, CH>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            acc[i] = fmaf(tab[vcode<BITS, i, WORDS>(w)], pt, acc[i]);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one token's 8..32 look-ups in flight at a time (VGPR budget)
+      });
+    });
+  };
+  for (int ci = 0; ci < n_chunks; ci += 2) {
+    chunk(std::integral_constant<int, 0>{}, ci);
+    if (ci + 1 < n_chunks) chunk(std::integral_constant<int, 1>{}, ci + 1);
   }
-  if (uvalid) {
-    float *slab = a.partial + ((int64_t)blockIdx.x * a.q_len + b) * C + (int64_t)u * CH;
+
+  // ---- sum the token slots through LDS (aliases the pipeline stages)
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(smem);
 #pragma unroll
-    for (int i = 0; i < CH; i += 4)
-      *reinterpret_cast<float4 *>(slab + i) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+  for (int i = 0; i < CH; i++) red[(i * Cfg::SLOTS + sl) * Cfg::UW + ul] = acc[i];
+  __syncthreads();
+  if (sl == 0 && ul < n_units_valid) {
+    float *dst = a.partial + ((int64_t)range * a.q_len + b) * C + (int64_t)(u0 + ul) * CH;
+    float o[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+      float s = red[(i * Cfg::SLOTS) * Cfg::UW + ul];
+#pragma unroll
+      for (int k = 1; k < Cfg::SLOTS; k++) s += red[(i * Cfg::SLOTS + k) * Cfg::UW + ul];
+      if (a.outliers != nullptr) s += sacc[ul * CH + i];
+      o[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < CH; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
   }
 }
 
-// mul[b][c] (+)= sum over slabs, fixed order
+// mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  32 channels x 8 range lanes per block, 8
+// independent loads in flight per lane.
 __global__ __launch_bounds__(256) void mix_v_reduce_kernel(const float *__restrict__ partial,
-                                                           float *__restrict__ mul, int n_ranges, int ubg,
-                                                           int n_sparse, int q_len, int C, int units_ch,
-                                                           int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+                                                           float *__restrict__ mul, int n_ranges, int q_len,
+                                                           int C, int accumulate) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   const int b = blockIdx.y;
-  if (c >= C) return;
-  // the dense slab of range r that holds channel c belongs to unit-block group g
-  const int g = (c / units_ch) / (kMixWaves * 64);
-  float s = accumulate ? mul[(int64_t)b * C + c] : 0.f;
-  for (int r = 0; r < n_ranges; r++) s += partial[((int64_t)(r * ubg + g) * q_len + b) * C + c];
-  for (int k = 0; k < n_sparse; k++) s += partial[((int64_t)(n_ranges * ubg + k) * q_len + b) * C + c];
-  mul[(int64_t)b * C + c] = s;
+  const int64_t stride = (int64_t)q_len * C;
+  float s = 0.f;
+  if (c < C) {
+    const float *src = partial + (int64_t)b * C + c;
+    int r = rg;
+    for (; r + 56 < n_ranges; r += 64) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(r + 8 * k) * stride];
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += v[k];
+    }
+    for (; r < n_ranges; r += 8) s += src[(int64_t)r * stride];
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) +
+              ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+    if (accumulate) t += mul[(int64_t)b * C + c];
+    mul[(int64_t)b * C + c] = t;
+  }
 }
 
-struct MixPlan {
+struct Plan {
   int64_t tr;
-  int n_ranges, ubg, n_units, n_sparse;
+  int n_ranges, groups, n_units;
   size_t bytes;
 };
 
-static MixPlan plan_mix(int bits, int q_len, int H, int64_t L, bool sparse) {
-  MixPlan pl;
-  const int ch = bits == 4 ? 8 : (bits == 3 ? 32 : 16);
-  pl.n_units = H * kHeadDim / ch;
-  const int ub = (pl.n_units + 63) / 64;
-  pl.ubg = (ub + kMixWaves - 1) / kMixWaves;
-  // ~1024 dense workgroups (4 per CU), ranges a multiple of the 64-token chunk
-  int64_t want = 1024 / pl.ubg;
+template <int BITS>
+static Plan plan_mix(int q_len, int H, int64_t L) {
+  using Cfg = VCfg<BITS>;
+  Plan pl;
+  pl.n_units = H * Cfg::UPH;
+  pl.groups = (pl.n_units + Cfg::UW - 1) / Cfg::UW;
+  int64_t want = 512 / pl.groups;   // two 512-lane workgroups per CU
   if (want < 1) want = 1;
   int64_t tr = (L + want - 1) / want;
-  tr = (tr + kChunk - 1) / kChunk * kChunk;
-  if (tr < 4 * kChunk) tr = 4 * kChunk;
+  tr = (tr + Cfg::CT - 1) / Cfg::CT * Cfg::CT;
+  if (tr < 2 * Cfg::CT) tr = 2 * Cfg::CT;
   pl.tr = tr;
   pl.n_ranges = (int)((L + tr - 1) / tr);
   if (pl.n_ranges < 1) pl.n_ranges = 1;
-  pl.n_sparse = sparse ? (int)((L + kSparseTokens - 1) / kSparseTokens) : 0;
-  pl.bytes = (size_t)(pl.n_ranges * pl.ubg + pl.n_sparse) * q_len * H * kHeadDim * sizeof(float);
+  pl.bytes = (size_t)pl.n_ranges * q_len * H * kHeadDim * sizeof(float);
   return pl;
 }
 
 template <int BITS>
-static int launch_mix(const MixVArgs &a, const MixPlan &pl, float *mul, int accumulate, hipStream_t st) {
-  const int C = a.H * kHeadDim;
-  dim3 grid(pl.n_ranges * pl.ubg + pl.n_sparse, 1, a.q_len), block(kMixWaves * 64);
+static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st) {
+  using Cfg = VCfg<BITS>;
+  Plan pl = plan_mix<BITS>(a.q_len, a.H, a.L);
+  a.tr = pl.tr;
+  a.groups = pl.groups;
+  a.n_units = pl.n_units;
+  dim3 grid(pl.n_ranges * pl.groups, 1, a.q_len), block(Cfg::NT);
   mix_v_kernel<BITS><<<grid, block, 0, st>>>(a);
   int rc = check_launch();
   if (rc) return rc;
-  dim3 rgrid((C + 255) / 256, a.q_len);
-  mix_v_reduce_kernel<<<rgrid, 256, 0, st>>>(a.partial, mul, pl.n_ranges, pl.ubg, pl.n_sparse, a.q_len, C,
-                                             Unit<BITS>::kCh, accumulate);
+  const int C = a.H * kHeadDim;
+  dim3 rgrid((C + 31) / 32, a.q_len);
+  mix_v_reduce_kernel<<<rgrid, 256, 0, st>>>(a.partial, mul, pl.n_ranges, a.q_len, C, accumulate);
   return check_launch();
+}
+
+static size_t ws_bytes(int bits, int q_len, int H, int64_t L) {
+  size_t a = bits == 4 ? plan_mix<4>(q_len, H, L).bytes : (bits == 3 ? plan_mix<3>(q_len, H, L).bytes : plan_mix<2>(q_len, H, L).bytes);
+  size_t b = plan_mix_rows(bits, q_len, H, L, true).bytes;
+  return a > b ? a : b;
 }
 
 }  // namespace kvq
@@ -251,8 +449,7 @@ extern "C" {
 
 size_t kvq_mix_v_workspace_bytes(int bits, int q_len, int H, int hd, int64_t L) {
   if (bits < 2 || bits > 4 || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0) return 0;
-  // sized for the sparse variant (a superset of the dense one)
-  return plan_mix(bits, q_len, H, L > 0 ? L : 1, true).bytes;
+  return ws_bytes(bits, q_len, H, L > 0 ? L : 1);
 }
 
 int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const float *lut_rows, int q_len,
@@ -270,9 +467,34 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
     }
     return KVQ_OK;
   }
-  MixPlan pl = plan_mix(bits, q_len, H, L, sparse);
-  if (!workspace || workspace_bytes < pl.bytes) return KVQ_EWORKSPACE;
-  MixVArgs a;
+  if (!workspace || workspace_bytes < ws_bytes(bits, q_len, H, L)) return KVQ_EWORKSPACE;
+  const bool fast = (max_len % 4 == 0) && (max_len >= 4) && ((int64_t)H * (hd / 32 * bits) * max_len < (1ll << 31)) &&
+                    ((reinterpret_cast<uintptr_t>(mat) | reinterpret_cast<uintptr_t>(lut_rows)) % 16 == 0);
+  if (!fast) {
+    MixPlan pl = plan_mix_rows(bits, q_len, H, L, sparse);
+    MixVArgs a;
+    a.p = p;
+    a.mat = reinterpret_cast<const uint32_t *>(mat);
+    a.lut_rows = lut_rows;
+    a.outliers = outliers;
+    a.idx = outlier_idx;
+    a.partial = reinterpret_cast<float *>(workspace);
+    a.H = H;
+    a.q_len = q_len;
+    a.L = L;
+    a.max_len = max_len;
+    a.tr = pl.tr;
+    a.n_ranges = pl.n_ranges;
+    a.ubg = pl.ubg;
+    a.n_units = pl.n_units;
+    a.n_out = n_out;
+    switch (bits) {
+      case 4: return launch_mix_rows<4>(a, pl, mul, accumulate, st);
+      case 3: return launch_mix_rows<3>(a, pl, mul, accumulate, st);
+      default: return launch_mix_rows<2>(a, pl, mul, accumulate, st);
+    }
+  }
+  MixArgs a;
   a.p = p;
   a.mat = reinterpret_cast<const uint32_t *>(mat);
   a.lut_rows = lut_rows;
@@ -283,15 +505,15 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
   a.q_len = q_len;
   a.L = L;
   a.max_len = max_len;
-  a.tr = pl.tr;
-  a.n_ranges = pl.n_ranges;
-  a.ubg = pl.ubg;
-  a.n_units = pl.n_units;
+  a.tr = 0;
+  a.groups = 1;
+  a.n_units = 0;
   a.n_out = n_out;
+  a.dbg = getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0;
   switch (bits) {
-    case 4: return launch_mix<4>(a, pl, mul, accumulate, st);
-    case 3: return launch_mix<3>(a, pl, mul, accumulate, st);
-    default: return launch_mix<2>(a, pl, mul, accumulate, st);
+    case 4: return launch_mix<4>(a, mul, accumulate, st);
+    case 3: return launch_mix<3>(a, mul, accumulate, st);
+    default: return launch_mix<2>(a, mul, accumulate, st);
   }
 }
 
