@@ -91,27 +91,20 @@ class Layer:
             done += S
 
 
-def decode_step(layers, qs, ks, vs, step, timers=None):
-    """one token through every layer's KV path; returns the last attention output"""
+def decode_step(layers, qs, ks, vs, step):
+    """one token through every layer's KV path (GPU-resident: 6 launches per layer, no host sync);
+    returns the last attention output"""
+    from kvquant_amd import ops
     inv = 1.0 / math.sqrt(HD)
     out = None
     for li, lay in enumerate(layers):
-        q = qs[li][step]
-        k = ks[li][step]
-        v = vs[li][step]
-        if timers is not None:
-            timers.begin("k")
-        scores = lay.k.forward_fused_sparse(q, k)                       # half [H,1,L]
-        if timers is not None:
-            timers.end("k")
-        # modeling_llama.py:1972-1977: fp16 scale, fp32 softmax, back to fp16
-        probs = torch.softmax(scores * inv, dim=-1, dtype=torch.float32).to(torch.float16)
-        if timers is not None:
-            timers.begin("v")
-        out = lay.v.forward_fused_sparse(probs, v)                      # half [H,1,hd]
-        if timers is not None:
-            timers.end("v")
-    return out
+        q = qs[li][step].float().transpose(0, 1).contiguous()         # [1,H,hd] f32 (ML:660-663)
+        k = ks[li][step].float()
+        v = vs[li][step].float()
+        scores = lay.k.append_and_score(q, k)                           # f32 [1,H,L]
+        probs, _ = ops.softmax_scale(scores[0], inv)                    # ML:873-874, 1972-1977
+        out = lay.v.append_and_mix(probs.unsqueeze(0), v)               # f32 [1,H,hd]
+    return out.half()
 
 
 class KernelTimers:

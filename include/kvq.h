@@ -128,6 +128,41 @@ KVQ_API int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul,
               int n_out, int accumulate, void *workspace, size_t workspace_bytes,
               void *stream);
 
+/* ---- GPU-resident decode append (replaces the reference's CPU topk round trips) -- */
+
+/* One launch = vecquant{b}appendvecKsparse + the host glue of
+ * QuantK.forward_fused_sparse (modeling_llama.py:706-751): top-thr_k largest and
+ * smallest rescaled values, residual = x - lut_off[c][n-1] / x - lut_off[c][0],
+ * zeroed where the rescaled value is inside [-1, 1], in ascending channel order,
+ * stored to row `col` of outliers / outlier_idx (width 2*thr_k).  lut_off = lut,
+ * or the Q-Norm table.  Ties at the selection boundary: lowest channel first
+ * (torch.topk leaves this unspecified).  H*hd <= 8192. */
+KVQ_API int kvq_append_k_fused(int bits, int32_t *mat, const float *lut,
+                       const float *lut_off, const float *x, const float *lo,
+                       const float *hi, float *outliers, int32_t *outlier_idx,
+                       int thr_k, int H, int hd, int64_t max_len, int64_t col,
+                       void *stream);
+
+/* One launch = the V top-(thr_k+1) selection of modeling_llama.py:1537-1545, the
+ * per-token codebook row lut_sorted*sf+off written to lut_rows[col] (1086-1114),
+ * vecquant{b}appendvecVsparse, and the sparse row (1168-1176).
+ * lut_sorted: float [2^bits] ascending. */
+KVQ_API int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows,
+                       const float *lut_sorted, const float *x, float *outliers,
+                       int32_t *outlier_idx, int thr_k, int H, int hd,
+                       int64_t max_len, int64_t col, void *stream);
+
+/* modeling_llama.py:873-874, 1950-1962, 1972-1977 in two launches: scores fp32
+ * [H][L] (raw q.K^T) -> half -> * inv_sqrt_hd (fp16) -> softmax in fp32 over
+ * [sink_scores | scores] -> fp16.  probs: the fp16 values widened to fp32, [H][L]
+ * (the layout kvq_mix_v reads); sink_scores / sink_probs: fp16 [H][n_sink]
+ * (already scaled; NULL when n_sink = 0). */
+KVQ_API size_t kvq_softmax_workspace_bytes(int H, int64_t L);
+KVQ_API int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores,
+                      float *probs, uint16_t *sink_probs, int H, int64_t L,
+                      int n_sink, float inv_sqrt_hd, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

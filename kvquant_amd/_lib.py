@@ -26,6 +26,10 @@ SIGNATURES = {
     "kvq_score_k": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp]),
     "kvq_mix_v_workspace_bytes": (_sz, [_i, _i, _i, _i, _i64]),
     "kvq_mix_v": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "kvq_append_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "kvq_append_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "kvq_softmax_workspace_bytes": (_sz, [_i, _i64]),
+    "kvq_softmax_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -138,19 +138,16 @@ class QuantK(nn.Module):
         vals = vals.masked_fill(zeros, 0.0)
         return vals, idx.int()
 
-    def forward_fused_sparse(self, q, k):
-        """ML:651-876.  q: [H, q_len, hd] post-RoPE query; k: the new pre-RoPE key
-        (C values).  Appends k and returns half [H, q_len, L] raw scores."""
-        k = k.flatten().float().contiguous()
-        q = q.float().transpose(0, 1).contiguous()
+    def append_and_score(self, q, k):
+        """The GPU-resident core of forward_fused_sparse: q f32 [q_len, H, hd] (post-RoPE),
+        k f32 [C] (pre-RoPE).  Appends k (pack + outlier row, one launch) and returns the raw
+        scores f32 [q_len, H, L] (one launch).  No host synchronisation."""
         pos = self.klen - self.first_few_fp16
         if self.include_sparse:
-            resc = torch.empty_like(k)
-            ops.append_k_sparse(self.bits, self.kcache, self.lookup_table, k, resc,
-                                self.outlier_threshold_lower, self.outlier_threshold_upper, pos)
-            vals, idx = self._outlier_rows(k.unsqueeze(0), resc.unsqueeze(0))
-            self.outliers[pos] = vals[0]
-            self.outlier_indices[pos] = idx[0]
+            lut_off = self.lookup_table2 if self.norm else self.lookup_table
+            ops.append_k_fused(self.bits, self.kcache, self.lookup_table, lut_off, k,
+                               self.outlier_threshold_lower, self.outlier_threshold_upper, self.outliers,
+                               self.outlier_indices, self.num_outliers // 2, pos)
         else:
             ops.append_k(self.bits, self.kcache, self.lookup_table, k, pos)
         self.klen += 1
@@ -163,6 +160,14 @@ class QuantK(nn.Module):
         else:
             ops.score_k(self.bits, q, self.kcache, mul, table, L, self.rope_theta, self.first_few_fp16,
                         accumulate=False)
+        return mul
+
+    def forward_fused_sparse(self, q, k):
+        """ML:651-876.  q: [H, q_len, hd] post-RoPE query; k: the new pre-RoPE key
+        (C values).  Appends k and returns half [H, q_len, L] raw scores."""
+        k = k.flatten().float().contiguous()
+        q = q.float().transpose(0, 1).contiguous()
+        mul = self.append_and_score(q, k)
         return mul.transpose(0, 1).contiguous().half()
 
     def parallel_pack(self, k):
@@ -255,14 +260,32 @@ class QuantV(nn.Module):
         lv, li = torch.topk(v_tok_major, k, dim=-1, largest=False)
         return uv, ui, lv, li
 
+    def append_and_mix(self, p, v):
+        """The GPU-resident core of forward_fused_sparse: p f32 [q_len, H, L+1] probabilities,
+        v f32 [C].  Appends v (thresholds, codebook row, pack, outlier row: one launch) and returns
+        f32 [q_len, H, hd] (two launches).  No host synchronisation.  include_sparse only."""
+        pos = self.vlen - self.first_few_fp16
+        ops.append_v_fused(self.bits, self.vcache, self.lookup_table, self.lut, v, self.outliers,
+                           self.outlier_indices, self.num_outliers // 2, pos)
+        self.vlen += 1
+        L = self.vlen - self.first_few_fp16
+        mul = torch.empty((p.shape[0], p.shape[1], self.head_dim), dtype=torch.float32, device=p.device)
+        ops.mix_v(self.bits, p, self.vcache, mul, self.lookup_table, L, self.outliers, self.outlier_indices,
+                  accumulate=False)
+        return mul
+
     def forward_fused_sparse(self, score, v, upper_outlier_vals=None, upper_outlier_indices=None,
                              lower_outlier_vals=None, lower_outlier_indices=None):
         """ML:1069-1291.  score: [H, q_len, L+1] probabilities; v: the new value
         (C values).  With include_sparse the four top-(thr+1) tensors may be passed as
-        in the reference or left None to be computed here on the GPU."""
+        in the reference (they are then used as given) or left None: selection then
+        happens inside the fused GPU append."""
         score = score.float()
         v_in = v.flatten()
         v = v_in.float().contiguous()
+        if self.include_sparse and upper_outlier_vals is None and not self.norm:
+            mul = self.append_and_mix(score.transpose(0, 1).contiguous(), v)
+            return mul.transpose(0, 1).contiguous().half()
         pos = self.vlen - self.first_few_fp16
         zc = ZERO_CODE[self.bits]
         if self.include_sparse:

@@ -1,0 +1,323 @@
+// GPU-resident decode append: NUQ pack + exact top-k outlier selection + outlier
+// row assembly in ONE launch per tensor, replacing the reference's
+//   kernel -> .cpu() -> torch.topk on the host -> 4 x .cuda() -> ~10 tiny GPU ops
+// round trip (modeling_llama.py:706-751 for K, 1803-1820 + 1086-1176 for V).
+//
+// One workgroup of 1024 lanes per token; lane l owns channels 4l..4l+3 (for
+// C = 4096; larger C loops).  Selection is an exact radix select on the
+// order-preserving integer image of the floats (4 passes of 8-bit digits, LDS
+// histograms), both tails at once.  Ties at the k-th value are broken by LOWEST
+// channel index (torch.topk leaves this unspecified).  The selected entries are
+// compacted in channel order with a ballot/prefix scan, which is exactly the
+// "sort by index" of the reference (modeling_llama.py:742, 1171), so no sort.
+#include "kvq_common.h"
+#include "kvq_host.h"
+
+namespace kvq {
+
+constexpr int kSelThreads = 1024;
+constexpr int kSelWaves = kSelThreads / 64;
+constexpr int kMaxPerLane = 8;  // channels per lane: C <= 8192
+
+__device__ __forceinline__ uint32_t fkey(float x) {  // ascending order-preserving
+  uint32_t b = __float_as_uint(x);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+struct SelShared {
+  uint32_t hist[2][256];
+  uint32_t wsum[kSelWaves + 1];
+  uint32_t prefix[2];
+  uint32_t krem[2];
+  uint32_t scan[kSelWaves];
+  unsigned codes[kMaxPerLane * kSelThreads];
+};
+
+// exclusive block scan of one uint per lane (wave shuffles + LDS across waves)
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, uint32_t &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();
+  if (lane == 63) ws[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kSelWaves; w++) {
+    const uint32_t s = ws[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  total = tot;
+  return base + inc - v;
+}
+
+// Exact k-th order statistics of both tails of keys[0..n) (n per lane valid):
+//   T[0] = key of the k-th LARGEST element, gt[0] = #keys > T[0]
+//   T[1] = key of the k-th SMALLEST element, gt[1] = #keys < T[1]
+template <int E>
+__device__ __forceinline__ void radix_select_both(const uint32_t (&key)[E], const bool (&ok)[E], uint32_t k,
+                                                  SelShared &sh, uint32_t (&T)[2], uint32_t (&gt)[2]) {
+  const int tid = threadIdx.x;
+  if (tid < 2) {
+    sh.prefix[tid] = 0;
+    sh.krem[tid] = k;
+  }
+  for (int pass = 3; pass >= 0; pass--) {
+    if (tid < 256) {
+      sh.hist[0][tid] = 0;
+      sh.hist[1][tid] = 0;
+    }
+    __syncthreads();
+    const uint32_t p0 = sh.prefix[0], p1 = sh.prefix[1];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (!ok[e]) continue;
+      const uint32_t kk = key[e];
+      const uint32_t hi = (pass == 3) ? 0u : (kk >> (8 * (pass + 1)));
+      const uint32_t d = (kk >> (8 * pass)) & 0xffu;
+      if (hi == p0) atomicAdd(&sh.hist[0][d], 1u);
+      if (hi == p1) atomicAdd(&sh.hist[1][d], 1u);
+    }
+    __syncthreads();
+    // wave 0 resolves the "largest" side (scan bins downward), wave 1 the "smallest" side (upward)
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < 2) {
+      const int side = wave;
+      // lane handles 4 consecutive bins in scan order
+      uint32_t c[4];
+      uint32_t s = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int pos = lane * 4 + j;                      // position in scan order
+        const int bin = side == 0 ? 255 - pos : pos;
+        c[j] = sh.hist[side][bin];
+        s += c[j];
+      }
+      uint32_t inc = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+      }
+      const uint32_t before = inc - s;                     // elements in bins scanned before this lane's
+      const uint32_t kr = sh.krem[side];
+      if (before < kr && kr <= inc) {                      // the k-th element is in one of my 4 bins
+        uint32_t run = before;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (run < kr && kr <= run + c[j]) {
+            const int pos = lane * 4 + j;
+            const int bin = side == 0 ? 255 - pos : pos;
+            sh.prefix[side] = (sh.prefix[side] << 8) | (uint32_t)bin;
+            sh.krem[side] = kr - run;                      // rank inside the chosen bin
+          }
+          run += c[j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  T[0] = sh.prefix[0];
+  T[1] = sh.prefix[1];
+  // after the last pass krem = rank among the elements EQUAL to T; #strictly beyond = k - krem
+  gt[0] = k - sh.krem[0];
+  gt[1] = k - sh.krem[1];
+}
+
+// mode 0: K (rescaled selection, per-channel LUT); mode 1: V (raw selection, per-token LUT built here)
+template <int BITS, bool IS_V>
+__global__ __launch_bounds__(kSelThreads) void fused_append_kernel(
+    uint32_t *__restrict__ mat, const float *__restrict__ lut /*K: [C][N]*/, const float *__restrict__ lut_off,
+    float *__restrict__ lut_rows /*V: [max_len][N]*/, const float *__restrict__ lut_sorted /*V: [N]*/,
+    const float *__restrict__ x, const float *__restrict__ lo, const float *__restrict__ hi,
+    float *__restrict__ outliers, int32_t *__restrict__ outlier_idx, int thr_k, int C, int64_t max_len,
+    int64_t col) {
+  constexpr int N = Fmt<BITS>::kN;
+  constexpr int E = kMaxPerLane;
+  __shared__ SelShared sh;
+  __shared__ float vrow[16];
+  const int tid = threadIdx.x;
+  const int per = (C + kSelThreads - 1) / kSelThreads;   // channels per lane (4 at C = 4096), <= E
+  const int c0 = tid * per;
+
+  float xv[E], sel[E];
+  uint32_t key[E];
+  bool ok[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    ok[e] = e < per && (c0 + e) < C;
+    xv[e] = ok[e] ? x[c0 + e] : 0.f;
+  }
+  if constexpr (!IS_V) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (!ok[e]) { sel[e] = 0.f; continue; }
+      const float l = lo[c0 + e], h = hi[c0 + e];
+      const float rangeval = (h - l) / 2;      // KCU:1759-1764
+      const float zeropoint = (h + l) / 2;
+      sel[e] = (xv[e] - zeropoint) / rangeval;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; e++) sel[e] = xv[e];
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) key[e] = fkey(sel[e]);
+
+  uint32_t T[2], gt[2];
+  const uint32_t ksel = IS_V ? (uint32_t)(thr_k + 1) : (uint32_t)thr_k;   // V: threshold is the (thr_k+1)-th
+  radix_select_both<E>(key, ok, ksel, sh, T, gt);
+
+  // ---- membership: strictly beyond the threshold, plus the first ties in channel order ----------
+  // K keeps k = thr_k per side; V keeps the top thr_k of the thr_k+1 selected (the last-ranked one,
+  // i.e. the highest-index tie, is the clipping threshold itself: modeling_llama.py:1091-1096).
+  uint32_t ntie_hi = 0, ntie_lo = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    if (!ok[e]) continue;
+    ntie_hi += key[e] == T[0];
+    ntie_lo += key[e] == T[1];
+  }
+  uint32_t tot;
+  const uint32_t packed = block_excl_scan(ntie_hi | (ntie_lo << 16), sh.scan, tot);
+  uint32_t rank_hi = packed & 0xffffu, rank_lo = packed >> 16;
+  const uint32_t want_hi = (uint32_t)thr_k - gt[0], want_lo = (uint32_t)thr_k - gt[1];
+  bool in_hi[E], in_lo[E];
+  uint32_t nsel = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    in_hi[e] = in_lo[e] = false;
+    if (!ok[e]) continue;
+    if (key[e] > T[0]) in_hi[e] = true;
+    else if (key[e] == T[0]) { in_hi[e] = rank_hi < want_hi; rank_hi++; }
+    if (key[e] < T[1]) in_lo[e] = true;
+    else if (key[e] == T[1]) { in_lo[e] = rank_lo < want_lo; rank_lo++; }
+    nsel += (in_hi[e] || in_lo[e]);
+  }
+
+  // ---- V: thresholds, scale/offset and the per-token codebook row ---------------------------------
+  float vmin = 0.f, vmax = 0.f, zp = 0.f;
+  if constexpr (IS_V) {
+    // threshold VALUES: decode the keys back
+    const uint32_t bh = T[0] ^ ((T[0] >> 31) ? 0x80000000u : 0xffffffffu);
+    const uint32_t bl = T[1] ^ ((T[1] >> 31) ? 0x80000000u : 0xffffffffu);
+    vmax = __uint_as_float(bh);
+    vmin = __uint_as_float(bl);
+    const float offset = (vmax + vmin) / 2;    // modeling_llama.py:1097-1098 (fp32)
+    const float sf = (vmax - vmin) / 2;
+    if (tid < N) {
+      const float r = lut_sorted[tid] * sf + offset;   // two roundings (-ffp-contract=off), ML:1113
+      vrow[tid] = r;
+      lut_rows[col * N + tid] = r;
+    }
+    __syncthreads();
+    zp = vrow[Fmt<BITS>::kZeroCode];
+  }
+
+  // ---- codes -------------------------------------------------------------------------------------
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    if (!ok[e]) continue;
+    float row[N];
+    if constexpr (IS_V) {
+#pragma unroll
+      for (int v = 0; v < N; v++) row[v] = vrow[v];
+    } else {
+      const float *src = lut + (int64_t)(c0 + e) * N;
+#pragma unroll
+      for (int v = 0; v < N; v += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(src + v);
+        row[v] = t.x; row[v + 1] = t.y; row[v + 2] = t.z; row[v + 3] = t.w;
+      }
+    }
+    unsigned code;
+    if constexpr (IS_V) code = (xv[e] < vmin || xv[e] > vmax) ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, xv[e]);
+    else code = nearest_code<N>(row, xv[e]);
+    sh.codes[c0 + e] = code;
+  }
+
+  // ---- outlier row: compaction in channel order ------------------------------------------------------
+  uint32_t tot2;
+  uint32_t pos = block_excl_scan(nsel, sh.scan, tot2);   // (the barriers inside also publish sh.codes)
+  const int n_out = 2 * thr_k;
+  float *orow = outliers + col * n_out;
+  int32_t *irow = outlier_idx + col * n_out;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    if (!ok[e] || !(in_hi[e] || in_lo[e])) continue;
+    float val;
+    if constexpr (IS_V) {
+      val = xv[e] - zp;                                   // modeling_llama.py:1169
+    } else {
+      const int c = c0 + e;
+      // residual to the saturated end point; zero when the rescaled value is inside [-1, 1]
+      // (modeling_llama.py:729-747)
+      if (in_hi[e]) val = (sel[e] <= 1.0f) ? 0.f : xv[e] - lut_off[(int64_t)c * N + (N - 1)];
+      else val = (sel[e] >= -1.0f) ? 0.f : xv[e] - lut_off[(int64_t)c * N];
+    }
+    if ((int)pos < n_out) {
+      orow[pos] = val;
+      irow[pos] = c0 + e;
+    }
+    pos++;
+  }
+
+  // ---- pack: one lane per 32-channel group ------------------------------------------------------------
+  for (int g = tid; g < C / 32; g += kSelThreads) {
+    unsigned cd[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) cd[i] = sh.codes[g * 32 + i];
+    uint32_t w[BITS];
+    pack32<BITS>(cd, w);
+#pragma unroll
+    for (int i = 0; i < BITS; i++) mat[((int64_t)g * BITS + i) * max_len + col] = w[i];
+  }
+}
+
+template <bool IS_V>
+static int launch_fused(int bits, int32_t *mat, const float *lut, const float *lut_off, float *lut_rows,
+                        const float *lut_sorted, const float *x, const float *lo, const float *hi,
+                        float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
+                        int64_t col, hipStream_t st) {
+  const int C = H * hd;
+  if (!mat || !x || !outliers || !outlier_idx || thr_k <= 0 || H <= 0 || hd <= 0 || hd % 32 || col < 0 ||
+      col >= max_len || C > kMaxPerLane * kSelThreads || 2 * (thr_k + 1) > C || C >= 65536)
+    return KVQ_EINVAL;
+  if (IS_V ? (!lut_rows || !lut_sorted) : (!lut || !lut_off || !lo || !hi)) return KVQ_EINVAL;
+  auto m = reinterpret_cast<uint32_t *>(mat);
+  dim3 grid(1), block(kSelThreads);
+  switch (bits) {
+    case 4: fused_append_kernel<4, IS_V><<<grid, block, 0, st>>>(m, lut, lut_off, lut_rows, lut_sorted, x, lo, hi, outliers, outlier_idx, thr_k, C, max_len, col); break;
+    case 3: fused_append_kernel<3, IS_V><<<grid, block, 0, st>>>(m, lut, lut_off, lut_rows, lut_sorted, x, lo, hi, outliers, outlier_idx, thr_k, C, max_len, col); break;
+    case 2: fused_append_kernel<2, IS_V><<<grid, block, 0, st>>>(m, lut, lut_off, lut_rows, lut_sorted, x, lo, hi, outliers, outlier_idx, thr_k, C, max_len, col); break;
+    default: return KVQ_EINVAL;
+  }
+  return check_launch();
+}
+
+}  // namespace kvq
+
+using namespace kvq;
+
+extern "C" {
+
+int kvq_append_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_off, const float *x,
+                       const float *lo, const float *hi, float *outliers, int32_t *outlier_idx, int thr_k,
+                       int H, int hd, int64_t max_len, int64_t col, void *stream) {
+  return launch_fused<false>(bits, mat, lut, lut_off, nullptr, nullptr, x, lo, hi, outliers, outlier_idx, thr_k,
+                             H, hd, max_len, col, (hipStream_t)stream);
+}
+
+int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
+                       float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
+                       int64_t col, void *stream) {
+  return launch_fused<true>(bits, mat, nullptr, nullptr, lut_rows, lut_sorted, x, nullptr, nullptr, outliers,
+                            outlier_idx, thr_k, H, hd, max_len, col, (hipStream_t)stream);
+}
+
+}  // extern "C"

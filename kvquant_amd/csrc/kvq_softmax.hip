@@ -1,0 +1,132 @@
+// Scale + softmax between the K score kernel and the V mix kernel, fused:
+// modeling_llama.py:873-874 (scores -> fp16), 1972-1973 (/sqrt(head_dim) in
+// fp16), 1950-1962 (fp16 attention-sink scores concatenated in front),
+// 1976 (softmax in fp32, result cast to fp16) -- five torch launches and three
+// dtype round trips in the reference.  Output: the fp16-rounded probabilities
+// widened back to fp32 in the [H][L] layout the V kernel consumes (what
+// `score.float()` produces at modeling_llama.py:1083), plus the sink part as
+// fp16.  Rows are split over several workgroups (two passes: partial max/sum,
+// then normalise) so that 32 heads fill the chip.
+#include "kvq_common.h"
+#include "kvq_host.h"
+
+#include <hip/hip_fp16.h>
+
+namespace kvq {
+
+// half(half(raw) * inv): the reference divides an fp16 tensor by a Python scalar
+// on the GPU, which torch evaluates as fp32 multiply by the fp32 reciprocal.
+__device__ __forceinline__ float scaled(float raw, float inv) {
+  const float h = __half2float(__float2half_rn(raw));
+  return __half2float(__float2half_rn(h * inv));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// pass 1: per (split, head) running max and sum of exp
+__global__ __launch_bounds__(256) void softmax_partial_kernel(const float *__restrict__ scores,
+                                                              const __half *__restrict__ sink, float *__restrict__ ws,
+                                                              int64_t L, int n_sink, float inv, int nsplit) {
+  __shared__ float red[8];
+  const int h = blockIdx.y, sp = blockIdx.x;
+  const int64_t per = (L + nsplit - 1) / nsplit;
+  const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
+  const float *row = scores + (int64_t)h * L;
+  float m = -INFINITY;
+  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) m = fmaxf(m, scaled(row[t], inv));
+  if (sp == 0)
+    for (int i = threadIdx.x; i < n_sink; i += 256) m = fmaxf(m, __half2float(sink[h * n_sink + i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  if (m > -INFINITY) {
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) s += expf(scaled(row[t], inv) - m);
+    if (sp == 0)
+      for (int i = threadIdx.x; i < n_sink; i += 256) s += expf(__half2float(sink[h * n_sink + i]) - m);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws[(h * nsplit + sp) * 2] = m;
+    ws[(h * nsplit + sp) * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+
+// pass 2: combine the partials of the row, normalise, round to fp16
+__global__ __launch_bounds__(256) void softmax_final_kernel(const float *__restrict__ scores,
+                                                            const __half *__restrict__ sink,
+                                                            const float *__restrict__ ws, float *__restrict__ probs,
+                                                            __half *__restrict__ sink_probs, int64_t L, int n_sink,
+                                                            float inv, int nsplit) {
+  const int h = blockIdx.y, sp = blockIdx.x;
+  float M = -INFINITY;
+  for (int i = 0; i < nsplit; i++) M = fmaxf(M, ws[(h * nsplit + i) * 2]);
+  float Z = 0.f;
+  for (int i = 0; i < nsplit; i++) {
+    const float mi = ws[(h * nsplit + i) * 2];
+    if (mi > -INFINITY) Z += ws[(h * nsplit + i) * 2 + 1] * expf(mi - M);
+  }
+  const int64_t per = (L + nsplit - 1) / nsplit;
+  const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
+  const float *row = scores + (int64_t)h * L;
+  float *out = probs + (int64_t)h * L;
+  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256)
+    out[t] = __half2float(__float2half_rn(expf(scaled(row[t], inv) - M) / Z));
+  if (sp == 0)
+    for (int i = threadIdx.x; i < n_sink; i += 256)
+      sink_probs[h * n_sink + i] = __float2half_rn(expf(__half2float(sink[h * n_sink + i]) - M) / Z);
+}
+
+static int pick_split(int H, int64_t L) {
+  int64_t s = 512 / (H > 0 ? H : 1);
+  const int64_t cap = (L + 1023) / 1024;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+}  // namespace kvq
+
+using namespace kvq;
+
+extern "C" {
+
+size_t kvq_softmax_workspace_bytes(int H, int64_t L) {
+  if (H <= 0 || L < 0) return 0;
+  return (size_t)H * pick_split(H, L) * 2 * sizeof(float);
+}
+
+int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores, float *probs, uint16_t *sink_probs,
+                      int H, int64_t L, int n_sink, float inv_sqrt_hd, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+  if (!scores || !probs || H <= 0 || L <= 0 || n_sink < 0) return KVQ_EINVAL;
+  if (n_sink > 0 && (!sink_scores || !sink_probs)) return KVQ_EINVAL;
+  if (!workspace || workspace_bytes < kvq_softmax_workspace_bytes(H, L)) return KVQ_EWORKSPACE;
+  const int nsplit = pick_split(H, L);
+  dim3 grid(nsplit, H), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  softmax_partial_kernel<<<grid, block, 0, st>>>(scores, reinterpret_cast<const __half *>(sink_scores),
+                                                 reinterpret_cast<float *>(workspace), L, n_sink, inv_sqrt_hd, nsplit);
+  int rc = check_launch();
+  if (rc) return rc;
+  softmax_final_kernel<<<grid, block, 0, st>>>(scores, reinterpret_cast<const __half *>(sink_scores),
+                                               reinterpret_cast<const float *>(workspace), probs,
+                                               reinterpret_cast<__half *>(sink_probs), L, n_sink, inv_sqrt_hd,
+                                               nsplit);
+  return check_launch();
+}
+
+}  // extern "C"

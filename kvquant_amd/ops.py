@@ -41,8 +41,8 @@ def _cache_dims(mat, bits):
     return H, W // bits * 32, max_len
 
 
-def _workspace(device, nbytes):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def _workspace(device, nbytes, slot="mix"):
+    key = (slot, device.index if device.index is not None else torch.cuda.current_device())
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -157,3 +157,48 @@ def mix_v(bits, p, mat, mul, lut_rows, L, outliers=None, outlier_indices=None, a
             int(L), max_len, None if outliers is None else _f(outliers, "outliers"),
             None if outliers is None else _i(outlier_indices, "outlier_indices"), n_out,
             1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "kvq_mix_v")
+
+
+def append_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, thr_k, col):
+    """pack + rescale + exact top-thr_k selection + outlier row, one launch (include/kvq.h)."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    if outliers.shape[1] != 2 * thr_k or outlier_indices.shape[1] != 2 * thr_k:
+        raise ValueError("outlier buffers must be %d wide" % (2 * thr_k))
+    with _Dev(mat):
+        _lib.check(_L().kvq_append_k_fused(bits, _i(mat, "mat"), _f(lut, "lookup_table"), _f(lut_off, "lut_off"),
+                                           _f(x, "newvec"), _f(lo, "lower"), _f(hi, "upper"),
+                                           _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"),
+                                           int(thr_k), H, hd, max_len, int(col), _stream()), "kvq_append_k_fused")
+
+
+def append_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col):
+    """top-(thr_k+1) thresholds + codebook row + pack + outlier row, one launch."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    if outliers.shape[1] != 2 * thr_k or outlier_indices.shape[1] != 2 * thr_k:
+        raise ValueError("outlier buffers must be %d wide" % (2 * thr_k))
+    if lut_sorted.numel() != 2 ** bits:
+        raise ValueError("lut_sorted must have 2^bits entries")
+    with _Dev(mat):
+        _lib.check(_L().kvq_append_v_fused(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"),
+                                           _f(lut_sorted, "lut"), _f(x, "newvec"), _f(outliers, "outliers"),
+                                           _i(outlier_indices, "outlier_indices"), int(thr_k), H, hd, max_len,
+                                           int(col), _stream()), "kvq_append_v_fused")
+
+
+def softmax_scale(scores, inv_sqrt_hd, sink_scores=None):
+    """scores: f32 [H, L] raw q.K^T; sink_scores: f16 [H, n_sink] already scaled, or None.
+    Returns (probs f32 [H, L] holding fp16-rounded values, sink_probs f16 [H, n_sink] or None)."""
+    if scores.dim() != 2:
+        raise ValueError("scores must be [H, L]")
+    H, L = scores.shape
+    n_sink = 0 if sink_scores is None else sink_scores.shape[1]
+    probs = torch.empty_like(scores)
+    sink_probs = None if sink_scores is None else torch.empty_like(sink_scores)
+    with _Dev(scores):
+        nbytes = _L().kvq_softmax_workspace_bytes(H, L)
+        ws = _workspace(scores.device, nbytes + (1 << 16), slot="softmax")
+        _lib.check(_L().kvq_softmax_scale(
+            _f(scores, "scores"), None if sink_scores is None else _chk(sink_scores, torch.float16, "sink_scores"),
+            _f(probs, "probs"), None if sink_probs is None else sink_probs.data_ptr(), H, L, n_sink,
+            float(inv_sqrt_hd), ws.data_ptr(), ws.numel(), _stream()), "kvq_softmax_scale")
+    return probs, sink_probs

@@ -1,0 +1,115 @@
+"""GPU parity of the GPU-resident decode path (fused append kernels + fused
+softmax) against the restated reference glue (oracle.glue, itself pinned to the
+reference's classes by tests/golden)."""
+import math
+
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+H, HD, C = util.H, util.HD, util.C
+
+
+def _quantizer(bits, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    scale = torch.exp(0.5 * torch.randn(C, generator=g))
+    shift = 0.3 * torch.randn(C, generator=g)
+    upper = (shift + 2.5 * scale).numpy()[None, :]
+    lower = (shift - 2.5 * scale).numpy()[None, :]
+    cent = util.centroids(bits)[torch.randperm(2 ** bits, generator=g)].numpy().reshape(-1, 1)
+    return (upper, lower, [cent]), scale, shift
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+@pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("sinks", [0, 5])
+def test_fused_decode_matches_oracle(gpu, bits, sinks):
+    from kvquant_amd.cache import QuantK, QuantV
+    from oracle.glue import OracleQuantK, OracleQuantV
+    quant, scale, shift = _quantizer(bits, seed=bits)
+    steps, max_len = 6, 16
+    ks = util.k_tokens(steps, scale, shift, seed=10 + bits)
+    vs = util.v_tokens(steps, seed=20 + bits)
+    g = torch.Generator().manual_seed(bits)
+    qs = torch.randn(steps, H, 1, HD, generator=g).half()
+    kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+              sparsity_threshold=0.99, first_few_fp16=sinks)
+    ok, ov = OracleQuantK(rope_theta=10000.0, **kw), OracleQuantV(**kw)
+    gk, gv = QuantK(rope_theta=10000.0, device=gpu, **kw), QuantV(device=gpu, **kw)
+    for c in (ok, ov, gk, gv):
+        c.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+    for c in (ok, gk):
+        c.klen += sinks
+    for c in (ov, gv):
+        c.vlen += sinks
+    for i in range(steps):
+        k16, v16, q16 = ks[i].half(), vs[i].half(), qs[i]
+        s_ref = ok.forward_fused_sparse(q16, k16)
+        s_gpu = gk.forward_fused_sparse(q16.to(gpu), k16.to(gpu))
+        assert util.rel_err(s_gpu.float().cpu(), s_ref.float()) < 2e-3
+        p = torch.softmax(s_ref.float() / math.sqrt(HD), dim=-1).half()
+        uv, ui, lv, li = OracleQuantV.topk_inputs(v16.float().unsqueeze(0), 0.99, C)
+        o_ref = ov.forward_fused_sparse(p, v16, uv[0], ui[0], lv[0], li[0])
+        o_gpu = gv.forward_fused_sparse(p.to(gpu), v16.to(gpu))          # selection inside the fused kernel
+        assert util.rel_err(o_gpu.float().cpu().reshape(1, -1), o_ref.float().reshape(1, -1)) < 2e-3
+    L = steps
+    assert torch.equal(ok.kcache[:, :, :L], gk.kcache[:, :, :L].cpu())
+    assert torch.equal(ov.vcache[:, :, :L], gv.vcache[:, :, :L].cpu())
+    assert torch.equal(ok.outlier_indices[:L], gk.outlier_indices[:L].cpu())
+    assert torch.equal(ok.outliers[:L].view(torch.int32), gk.outliers[:L].cpu().view(torch.int32))
+    assert torch.equal(ov.outlier_indices[:L], gv.outlier_indices[:L].cpu())
+    assert torch.equal(ov.outliers[:L].view(torch.int32), gv.outliers[:L].cpu().view(torch.int32))
+    assert torch.equal(ov.lookup_table[:L].view(torch.int32), gv.lookup_table[:L].cpu().view(torch.int32))
+
+
+def test_fused_selection_with_ties(gpu):
+    """ties at the selection boundary: torch.topk's choice among equal values is unspecified;
+    ours is 'lowest channel first'.  The selected VALUES and thresholds must still agree."""
+    from kvquant_amd import ops
+    bits, n = 4, 16
+    x = torch.zeros(C)
+    x[100:140] = 3.0          # 40 equal maxima, only 21 can be kept
+    x[2000:2050] = -2.0       # 50 equal minima
+    x[7] = 5.0
+    lut = util.centroids(bits)
+    mat = torch.zeros(H, 16, 4, dtype=torch.int32, device=gpu)
+    rows = torch.zeros(4, n, device=gpu)
+    outl = torch.zeros(4, 42, device=gpu)
+    oidx = torch.zeros(4, 42, dtype=torch.int32, device=gpu)
+    ops.append_v_fused(bits, mat, rows, lut.to(gpu), x.to(gpu), outl, oidx, 21, 1)
+    idx = oidx[1].cpu()
+    assert torch.equal(idx, torch.sort(idx).values)
+    assert len(set(idx.tolist())) == 42
+    expect_hi = [7] + list(range(100, 120))           # 5.0, then the 20 lowest-index 3.0s
+    expect_lo = list(range(2000, 2021))
+    assert sorted(idx.tolist()) == sorted(expect_hi + expect_lo)
+    # thresholds: 22nd largest = 3.0, 22nd smallest = -2.0
+    r = rows[1].cpu()
+    assert torch.allclose(r, lut * 2.5 + 0.5)
+
+
+@pytest.mark.parametrize("L,n_sink", [(1, 0), (1000, 0), (40000, 5), (131073, 0)])
+def test_softmax_scale(gpu, L, n_sink):
+    from kvquant_amd import ops
+    g = torch.Generator().manual_seed(L)
+    raw = (torch.randn(H, L, generator=g) * 30).to(gpu)
+    inv = 1.0 / math.sqrt(HD)
+    sink = (torch.randn(H, n_sink, generator=g) * 3).half().to(gpu) if n_sink else None
+    probs, sp = ops.softmax_scale(raw, inv, sink)
+    s16 = (raw.half() / math.sqrt(HD))                       # fp16 tensor / python scalar, as ML:1972-1973
+    full = s16 if sink is None else torch.cat((sink, s16), dim=-1)
+    ref = torch.softmax(full, dim=-1, dtype=torch.float32).half()
+    got = probs.half() if sink is None else torch.cat((sp, probs.half()), dim=-1)
+    assert torch.equal(probs, probs.half().float())          # values are fp16-representable
+    d = (got.float() - ref.float()).abs()
+    tol = ref.float().abs() * 2e-3 + 1e-7                    # 1-2 fp16 ulp
+    assert bool((d <= tol).all()), float((d - tol).max())
+    assert abs(float(got.float().sum(-1).mean()) - 1.0) < 5e-3
