@@ -47,20 +47,37 @@ struct ScoreKArgs {
   int accumulate;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS image of one head's codebook, pre-multiplied by the query.  Rotation pair i (0..31) of
+// wave-half ("role") r covers channel k_lo = 32r+i and k_hi = 64+32r+i.  Entry order:
+//   TLO[(i*2 + r)*N + code] = (L[k_lo][code]*q[k_lo],  L[k_lo][code]*q[k_lo+64])
+//   THI[(i*2 + r)*N + code] = (L[k_hi][code]*q[k_hi], -L[k_hi][code]*q[k_hi-64])
+// so the variable part of a look-up address is (r*N + code)*8 bytes -- for 4 bit that is ONE byte
+// (role in bit 7, code*8 below) which a single v_bfe_u32 cuts out of a pre-masked word -- and the
+// pair index i is an instruction immediate.
 template <int BITS>
-__device__ __forceinline__ void stage_lutq(float2 *dst, const float *__restrict__ lut,
+struct KTab {
+  static constexpr int N = Fmt<BITS>::kN;
+  static constexpr int HALF_B = 32 * 2 * N * 8;     // bytes of TLO (= THI)
+  static constexpr int BUF_B = 2 * HALF_B;          // one head
+};
+
+template <int BITS>
+__device__ __forceinline__ void stage_lutq(unsigned char *dst, const float *__restrict__ lut,
                                            const float *__restrict__ qh, int nthreads) {
   constexpr int N = Fmt<BITS>::kN;
   for (int e4 = threadIdx.x; e4 < kHeadDim * N / 4; e4 += nthreads) {
     const int e0 = e4 * 4;
-    const int k = e0 / N;
+    const int k = e0 / N, v0 = e0 % N;
     const float4 l4 = *reinterpret_cast<const float4 *>(lut + e0);
     const float qa = qh[k];
     const float qb = (k < 64) ? qh[k + 64] : -qh[k - 64];
-    float4 o0 = make_float4(l4.x * qa, l4.x * qb, l4.y * qa, l4.y * qb);
-    float4 o1 = make_float4(l4.z * qa, l4.z * qb, l4.w * qa, l4.w * qb);
-    *reinterpret_cast<float4 *>(dst + e0) = o0;
-    *reinterpret_cast<float4 *>(dst + e0 + 2) = o1;
+    const int kk = k & 63;
+    const int r = kk >> 5, i = kk & 31;
+    float4 *d = reinterpret_cast<float4 *>(dst + (k >> 6) * KTab<BITS>::HALF_B + (((i * 2 + r) * N + v0) << 3));
+    d[0] = make_float4(l4.x * qa, l4.x * qb, l4.y * qa, l4.y * qb);
+    d[1] = make_float4(l4.z * qa, l4.z * qb, l4.w * qa, l4.w * qb);
   }
 }
 
@@ -71,17 +88,24 @@ __device__ __forceinline__ void load_words(uint32_t (&w)[BITS], const uint32_t *
   for (int i = 0; i < BITS; i++) w[i] = __builtin_nontemporal_load(mat + (row0 + i) * max_len + t);
 }
 
+constexpr int kSparseHpg = 16;   // heads per workgroup cap of the sparse variant (LDS budget)
+
 template <int BITS, bool SPARSE, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
   constexpr int N = Fmt<BITS>::kN;
   constexpr int WPH = Fmt<BITS>::kWordsPerHead;
   constexpr int T = NWAVES * 32;
   constexpr int NT = NWAVES * 64;
+  constexpr int TAB_B = KTab<BITS>::BUF_B;
+  constexpr int SC_B = SPARSE ? kSparseHpg * T * 4 : 16;
+  constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 16;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2 *lutq = reinterpret_cast<float2 *>(smem);                       // [2][128*N]
-  float *theta = reinterpret_cast<float *>(smem + 2 * kHeadDim * N * 8);  // [64]
-  float *sc = theta + 64;                                                 // [hpg][T]
+  // static LDS: every table offset below is a compile-time constant that folds into ds immediates
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TAB_B + 256 + SC_B + QL_B];
+  unsigned char *lutq = smem;                                                    // [2][TAB_B]
+  float *theta = reinterpret_cast<float *>(smem + 2 * TAB_B);                    // [64]
+  float *sc = reinterpret_cast<float *>(smem + 2 * TAB_B + 256);                 // [hpg][T]
+  float *ql = reinterpret_cast<float *>(smem + 2 * TAB_B + 256 + SC_B);          // [hpg][128]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,6 +123,7 @@ __global__ __launch_bounds__(NWAVES * 64) void score_k_kernel(ScoreKArgs a, Rope
   if (tid < 64) theta[tid] = fr.f[tid];
   if constexpr (SPARSE) {
     for (int i = tid; i < a.hpg * T; i += NT) sc[i] = 0.f;
+    for (int i = tid; i < a.hpg * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
   }
   stage_lutq<BITS>(lutq, a.lut + (int64_t)h0 * kHeadDim * N, qb + h0 * kHeadDim, NT);
 
@@ -110,60 +135,88 @@ __global__ __launch_bounds__(NWAVES * 64) void score_k_kernel(ScoreKArgs a, Rope
   __syncthreads();
 
   // RoPE angles of this lane's token for its 32 rotation pairs (KCU:3083, 3122-3123)
-  float cs[32], sn[32];
+  f32x2 cs[32];   // (cos, sin)
   const float posf = (float)((int)tc + a.pos_offset);
   static_for<0, 32>([&](auto I) {
     constexpr int i = decltype(I)::value;
     const float ang = theta[role * 32 + i] * posf;
-    sincos_rev(ang, sn[i], cs[i]);
+    float sn, c;
+    sincos_rev(ang, sn, c);
+    cs[i].x = c;
+    cs[i].y = sn;
   });
 
   if constexpr (SPARSE) {
     if (b == 0 && a.outliers != nullptr) {  // reference: sparse part ignores q_len > 1 (KCU:3605)
-      const int64_t ntok = (a.L - tile0 < T) ? (a.L - tile0) : T;
-      const int64_t nent = ntok * a.n_out;
+      const int ntok = (a.L - tile0 < T) ? (int)(a.L - tile0) : T;
+      const unsigned nent = (unsigned)ntok * (unsigned)a.n_out;
       const float *ov = a.outliers + tile0 * a.n_out;
       const int32_t *oi = a.idx + tile0 * a.n_out;
-      for (int64_t e = tid; e < nent; e += NT) {
+      const int pos0 = (int)tile0 + a.pos_offset;
+      for (unsigned e = tid; e < nent; e += NT) {
         const float val = ov[e];
-        if (val == 0.f) continue;  // capped slots that were not outliers (modeling_llama.py:745-747)
         const int col = oi[e];
-        const int head = col >> 7;
-        const int hh = head - h0;
-        if (hh < 0 || hh >= a.hpg) continue;
-        const int tle = (int)(e / a.n_out);
+        const int hh = (col >> 7) - h0;
+        if (val == 0.f || (unsigned)hh >= (unsigned)a.hpg) continue;   // capped-away slot / other head group
+        const unsigned tle = e / (unsigned)a.n_out;
         const int ch = col & 127;
-        const float ang = theta[ch & 63] * (float)((int)(tile0 + tle) + a.pos_offset);
+        const float ang = theta[ch & 63] * (float)(pos0 + (int)tle);
         float s, c;
         sincos_rev(ang, s, c);
-        const float q1 = qb[col];
-        const float q2 = qb[(head << 7) + ((ch + 64) & 127)];
+        const float q1 = ql[hh * kHeadDim + ch];
+        const float q2 = ql[hh * kHeadDim + ((ch + 64) & 127)];
         const float sg = (ch < 64) ? s : -s;
         atomicAdd(&sc[hh * T + tle], val * fmaf(c, q1, sg * q2));
       }
     }
   }
 
-  for (int hh = 0; hh < a.hpg; hh++) {
+  // per-lane constant part of every look-up address
+  const uint32_t rolepat = role ? 0x80808080u : 0u;     // 4 bit: role*128 in every byte
+  const uint32_t rolebytes = (uint32_t)role * N * 8;    // generic
+
+  auto head = [&](auto BUF, int hh) {
+    constexpr int buf = decltype(BUF)::value;
     const int h = h0 + hh;
-    __syncthreads();  // lutq[hh&1] staged (and sc complete); lutq[(hh+1)&1] free
-    const float2 *tab = lutq + (hh & 1) * (kHeadDim * N) + role * 32 * N;
+    __syncthreads();  // table `buf` staged (and sc complete); the other table is free
     uint32_t nlo[BITS], nhi[BITS];
     if (hh + 1 < a.hpg) {
-      stage_lutq<BITS>(lutq + ((hh + 1) & 1) * (kHeadDim * N), a.lut + (int64_t)(h + 1) * kHeadDim * N,
-                       qb + (h + 1) * kHeadDim, NT);
+      stage_lutq<BITS>(lutq + (1 - buf) * TAB_B, a.lut + (int64_t)(h + 1) * kHeadDim * N, qb + (h + 1) * kHeadDim, NT);
       load_words<BITS>(nlo, a.mat, (int64_t)(h + 1) * WPH + role * BITS, a.max_len, tc);
       load_words<BITS>(nhi, a.mat, (int64_t)(h + 1) * WPH + (2 + role) * BITS, a.max_len, tc);
     }
-    float r0 = 0.f, r1 = 0.f;
-    static_for<0, 32>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      const float2 lo = tab[i * N + code_of<BITS, i>(wlo)];
-      const float2 hi = tab[(64 + i) * N + code_of<BITS, i>(whi)];
-      r0 = fmaf(cs[i], lo.x + hi.x, r0);
-      r1 = fmaf(sn[i], lo.y + hi.y, r1);
-    });
-    float res = r0 + r1;
+    const unsigned char *tlo = lutq + buf * TAB_B;
+    const unsigned char *thi = lutq + buf * TAB_B + KTab<BITS>::HALF_B;
+    f32x2 acc = {0.f, 0.f};
+    if constexpr (BITS == 4) {
+      static_for<0, 4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        // even / odd nibbles as bytes = role*128 + code*8
+        const uint32_t elo = ((wlo[j] << 3) & 0x78787878u) | rolepat, olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
+        const uint32_t ehi = ((whi[j] << 3) & 0x78787878u) | rolepat, ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
+        static_for<0, 8>([&](auto NN) {
+          constexpr int n = decltype(NN)::value;
+          constexpr int i = 8 * j + n;
+          const uint32_t fl = (((n & 1) ? olo : elo) >> (8 * (n / 2))) & 0xffu;
+          const uint32_t fh = (((n & 1) ? ohi : ehi) >> (8 * (n / 2))) & 0xffu;
+          const f32x2 lo = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
+          const f32x2 hi = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+          acc = __builtin_elementwise_fma(cs[i], lo, acc);
+          acc = __builtin_elementwise_fma(cs[i], hi, acc);
+        });
+      });
+    } else {
+      static_for<0, 32>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t fl = (code_of<BITS, i>(wlo) << 3) + rolebytes;
+        const uint32_t fh = (code_of<BITS, i>(whi) << 3) + rolebytes;
+        const f32x2 lo = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
+        const f32x2 hi = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+        acc = __builtin_elementwise_fma(cs[i], lo, acc);
+        acc = __builtin_elementwise_fma(cs[i], hi, acc);
+      });
+    }
+    float res = acc.x + acc.y;
     res += __shfl_xor(res, 32);
     if (role == 0 && valid) {
       if constexpr (SPARSE) res += sc[hh * T + tl];
@@ -178,6 +231,10 @@ __global__ __launch_bounds__(NWAVES * 64) void score_k_kernel(ScoreKArgs a, Rope
         whi[i] = nhi[i];
       }
     }
+  };
+  for (int hh = 0; hh < a.hpg; hh += 2) {
+    head(std::integral_constant<int, 0>{}, hh);
+    if (hh + 1 < a.hpg) head(std::integral_constant<int, 1>{}, hh + 1);
   }
 }
 
@@ -192,15 +249,15 @@ static RopeFreqs make_freqs(float rope_theta) {
   return fr;
 }
 
-static int pick_groups(int H, int64_t tiles) {
-  // enough workgroups to fill 256 CUs twice over, heads per group as large as
-  // possible (trig amortisation); groups must divide H.
+static int pick_groups(int H, int64_t tiles, int max_hpg) {
+  // enough workgroups to fill 256 CUs twice over, heads per group as large as possible (trig
+  // amortisation) but <= max_hpg; groups must divide H.
   int64_t want = (512 + tiles - 1) / tiles;
-  int g = 1;
+  int g = H;
   for (int d = 1; d <= H; d++)
-    if (H % d == 0) {
+    if (H % d == 0 && H / d <= max_hpg && d >= want) {
       g = d;
-      if (d >= want) break;
+      break;
     }
   return g;
 }
@@ -208,20 +265,12 @@ static int pick_groups(int H, int64_t tiles) {
 template <int BITS, bool SPARSE, int NWAVES>
 static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipStream_t st) {
   constexpr int T = NWAVES * 32;
-  constexpr int N = Fmt<BITS>::kN;
   ScoreKArgs a = a0;
   const int64_t tiles = (a.L + T - 1) / T;
-  const int groups = pick_groups(a.H, tiles);
+  const int groups = pick_groups(a.H, tiles, SPARSE ? kSparseHpg : 1 << 30);
   a.hpg = a.H / groups;
-  size_t smem = 2 * kHeadDim * N * 8 + 64 * 4 + (SPARSE ? (size_t)a.hpg * T * 4 : 0);
   dim3 grid((unsigned)tiles, groups, q_len), block(NWAVES * 64);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&score_k_kernel<BITS, SPARSE, NWAVES>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  score_k_kernel<BITS, SPARSE, NWAVES><<<grid, block, smem, st>>>(a, make_freqs(rope_theta));
+  score_k_kernel<BITS, SPARSE, NWAVES><<<grid, block, 0, st>>>(a, make_freqs(rope_theta));
   return check_launch();
 }
 

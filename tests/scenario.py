@@ -84,10 +84,34 @@ EXACT_KEYS = ["k_lookup_table", "k_thr_upper", "k_thr_lower", "v_lut", "kcache",
               "k_outliers", "k_outlier_indices", "v_outliers", "v_outlier_indices"]
 
 
-def compare(g, out, exact_scores=False, rtol=1e-3):
+def _v_rows_equal_up_to_ties(g, out):
+    """torch.topk does not define WHICH of several equal values it returns.  The fused GPU
+    selection breaks ties by lowest channel; the fixture holds torch's choice.  Accept a row
+    iff the selected values agree as multisets and every index that differs points at a value
+    equal to the one it replaces."""
+    sinks = int(g["sinks"])
+    v_all = g["v_all"].astype(np.float32)
+    for t in range(g["v_outliers"].shape[0]):
+        a_v, b_v = g["v_outliers"][t], out["v_outliers"][t]
+        a_i, b_i = g["v_outlier_indices"][t], out["v_outlier_indices"][t]
+        if np.array_equal(a_i, b_i) and np.array_equal(a_v.view(np.uint32), b_v.view(np.uint32)):
+            continue
+        assert np.array_equal(np.sort(a_v).view(np.uint32), np.sort(b_v).view(np.uint32)), "row %d values" % t
+        x = v_all[sinks + t]
+        only_a = sorted(set(a_i.tolist()) - set(b_i.tolist()))
+        only_b = sorted(set(b_i.tolist()) - set(a_i.tolist()))
+        assert len(only_a) == len(only_b)
+        assert sorted(x[only_a].tolist()) == sorted(x[only_b].tolist()), "row %d: not a tie" % t
+        assert np.array_equal(b_i, np.sort(b_i)), "row %d not sorted by channel" % t
+
+
+def compare(g, out, exact_scores=False, rtol=1e-3, v_ties_ok=False):
     """bit-exact on packed caches / LUTs / outlier rows; scores and outputs within
     1e-3 relative (of the row's max magnitude) in fp16, the north-star tolerance."""
     for k in EXACT_KEYS:
+        if v_ties_ok and k in ("v_outliers", "v_outlier_indices") and k in g:
+            _v_rows_equal_up_to_ties(g, out)
+            continue
         if k in g:
             a, b = g[k], out[k]
             assert a.shape == b.shape, (k, a.shape, b.shape)

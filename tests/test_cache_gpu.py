@@ -25,4 +25,5 @@ def test_cache_classes_match_reference_golden(path, host_topk):
     from kvquant_amd.cache import QuantK, QuantV
     g = scenario.load(path)
     out = scenario.replay(g, QuantK, QuantV, device="cuda", v_topk_on_host=host_topk)
-    scenario.compare(g, out)
+    # with selection on the GPU only boundary TIES may be resolved differently from torch.topk
+    scenario.compare(g, out, v_ties_ok=not host_topk)
