@@ -108,12 +108,16 @@ KVQ_API int kvq_pack_v_sparse_parallel(int bits, int32_t *mat, const float *lut_
  * Khat = LUT value + the token's sparse residuals when outliers != NULL (the
  * sparse part only for b = 0, as the reference).  q: float [q_len][H][128];
  * mul: float [q_len][H][L].  accumulate != 0: add into mul (the reference's
- * pre-zeroed contract); 0: overwrite. */
+ * pre-zeroed contract); 0: overwrite.  Needs a 16-byte aligned device workspace of
+ * kvq_score_k_workspace_bytes(...) bytes (the query-premultiplied codebook
+ * images, H * 2^bits KiB). */
+KVQ_API size_t kvq_score_k_workspace_bytes(int bits, int q_len, int H);
 KVQ_API int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul,
                 const float *lut, int q_len, int H, int hd, int64_t L,
                 int64_t max_len, float rope_theta, int pos_offset,
                 const float *outliers, const int32_t *outlier_idx, int n_out,
-                int accumulate, void *stream);
+                int accumulate, void *workspace, size_t workspace_bytes,
+                void *stream);
 
 /* vecquant{b}matmul_nuq_perchannel_transposed_mha_batched_fused_opt and
  * ..._opt2 (KCPP:214-238 ...; KCU:3211-3433, 3491-3538, 3625-3690, 437-470):

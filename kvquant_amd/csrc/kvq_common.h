@@ -115,4 +115,32 @@ struct RopeFreqs {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// ---- LDS-DMA (global_load_lds) -------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+
+// LDS-DMA issued from inline asm so that hipcc does not put it on its own vmcnt scoreboard (with the
+// builtin it waits vmcnt(0) in front of every later ds_read and the copy never overlaps the math;
+// cdna_hip_programming.md 5.7).  lds_dst: wave-uniform LDS byte address (goes to M0), gsrc: per-lane
+// source.  Completion is waited for explicitly (dma_wait_all) before the barrier that publishes a stage.
+__device__ __forceinline__ void dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;   // source = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(const lds_byte_t *)p;
+}
+// wait until at most N of this wave's VMEM operations (DMA pieces and ordinary loads, in issue order)
+// are still outstanding
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 }  // namespace kvq

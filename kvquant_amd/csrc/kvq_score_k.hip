@@ -7,27 +7,35 @@
 //   * a workgroup owns a tile of T = 32*NWAVES cached tokens and a group of
 //     heads.  The RoPE angles of a token depend only on (token, j) -- not on
 //     the head -- so each lane evaluates the sincos of ITS token once per tile
-//     and reuses it for every head of the group (the reference evaluates 256
-//     transcendentals per (token, head));
+//     (hardware v_sin/v_cos after an exact hi/lo range reduction) and reuses it
+//     for every head of the group; the reference evaluates 256 transcendentals
+//     per (token, head);
 //   * a wave is split in two 32-lane halves that serve the same 32 tokens:
-//     half r handles rotation pairs j in [32r, 32r+32), i.e. channels
+//     half r handles rotation pairs i in [32r, 32r+32), i.e. channels
 //     [32r,32r+32) and [64+32r, 64+32r+32).  That halves the trig registers
 //     (64 VGPRs) and keeps the two halves in different LDS lane groups;
-//   * per head the 128 x 2^bits codebook is staged in LDS PRE-MULTIPLIED by
-//     the query: entry (k, v) = (L*q[k], sgn_k*L*q[(k+64)%128]).  One
-//     conflict-free ds_read_b64 per code (all lanes of a 32-lane group read the
-//     same channel k; the 2^bits distinct addresses fall into distinct banks)
-//     yields both RoPE operands, so a code costs 2 address ops + 2 FMAs;
+//   * the per-head codebook, PRE-MULTIPLIED by the query, is built once per
+//     call by a tiny kernel (entry = (L*q[k], sgn_k*L*q[(k+64)%128])) as the
+//     exact LDS image and copied per head with LDS-DMA one head ahead of the
+//     math (no VALU, no registers, no ds_write).  One conflict-free
+//     ds_read_b64 per code yields both RoPE operands and feeds one packed FMA
+//     against the lane's (cos, sin) pair.  The variable part of a look-up
+//     address is one byte (role*128 + code*8) cut out of a pre-masked word by
+//     a single v_bfe_u32; everything else is an instruction immediate (static
+//     LDS);
 //   * packed words are read with lanes along the token axis (the contiguous
-//     axis): 128 B per half-wave per row, prefetched one head ahead;
+//     axis): 128 B per half-wave per row, two heads ahead of the math;
 //   * the sparse residuals of the tile are scattered into an LDS score tile
-//     with ds_add_f32 before the dense loop and folded into the single store of
-//     each score (no global atomics; the reference does one per outlier).
+//     with ds_add_f32 before the dense loop (entries fetched in batches so the
+//     HBM latency is paid three times per tile, not once per entry) and folded
+//     into the single store of each score: no global atomics, one store per
+//     score (the reference does one atomic per outlier and one per score).
 // Algorithmic HBM bytes per cached token: C*bits/8 (+ 8*n_out sparse) + 4*H.
 #include "kvq_common.h"
 #include "kvq_host.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace kvq {
 
@@ -35,7 +43,7 @@ struct ScoreKArgs {
   const float *q;          // [q_len][H][128]
   const uint32_t *mat;     // [H][WPH][max_len]
   float *mul;              // [q_len][H][L]
-  const float *lut;        // [H][128][N]
+  const unsigned char *tab;  // [q_len][H][TAB_B] pre-multiplied codebook images (workspace)
   const float *outliers;   // [max_len][n_out] or null
   const int32_t *idx;
   int H;
@@ -44,6 +52,7 @@ struct ScoreKArgs {
   int64_t max_len;
   int pos_offset;
   int n_out;
+  uint32_t n_out_magic;    // ceil(2^32 / n_out): e / n_out == umulhi(e, magic) for e < 2^32 / n_out
   int accumulate;
 };
 
@@ -53,9 +62,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // wave-half ("role") r covers channel k_lo = 32r+i and k_hi = 64+32r+i.  Entry order:
 //   TLO[(i*2 + r)*N + code] = (L[k_lo][code]*q[k_lo],  L[k_lo][code]*q[k_lo+64])
 //   THI[(i*2 + r)*N + code] = (L[k_hi][code]*q[k_hi], -L[k_hi][code]*q[k_hi-64])
-// so the variable part of a look-up address is (r*N + code)*8 bytes -- for 4 bit that is ONE byte
-// (role in bit 7, code*8 below) which a single v_bfe_u32 cuts out of a pre-masked word -- and the
-// pair index i is an instruction immediate.
 template <int BITS>
 struct KTab {
   static constexpr int N = Fmt<BITS>::kN;
@@ -63,14 +69,19 @@ struct KTab {
   static constexpr int BUF_B = 2 * HALF_B;          // one head
 };
 
+// one workgroup per (head, query row): builds the image in global memory (L2-resident: H*16 KB)
 template <int BITS>
-__device__ __forceinline__ void stage_lutq(unsigned char *dst, const float *__restrict__ lut,
-                                           const float *__restrict__ qh, int nthreads) {
+__global__ __launch_bounds__(256) void lutq_prep_kernel(const float *__restrict__ lut, const float *__restrict__ q,
+                                                        unsigned char *__restrict__ tab, int H) {
   constexpr int N = Fmt<BITS>::kN;
-  for (int e4 = threadIdx.x; e4 < kHeadDim * N / 4; e4 += nthreads) {
+  const int h = blockIdx.x, b = blockIdx.y;
+  const float *lh = lut + (int64_t)h * kHeadDim * N;
+  const float *qh = q + ((int64_t)b * H + h) * kHeadDim;
+  unsigned char *dst = tab + ((int64_t)b * H + h) * KTab<BITS>::BUF_B;
+  for (int e4 = threadIdx.x; e4 < kHeadDim * N / 4; e4 += 256) {
     const int e0 = e4 * 4;
     const int k = e0 / N, v0 = e0 % N;
-    const float4 l4 = *reinterpret_cast<const float4 *>(lut + e0);
+    const float4 l4 = *reinterpret_cast<const float4 *>(lh + e0);
     const float qa = qh[k];
     const float qb = (k < 64) ? qh[k + 64] : -qh[k - 64];
     const int kk = k & 63;
@@ -81,35 +92,63 @@ __device__ __forceinline__ void stage_lutq(unsigned char *dst, const float *__re
   }
 }
 
+// BITS consecutive word-rows starting at uniform row `row0`, each read at the lane's byte offset `voff`:
+// wave-uniform 64-bit row base in SGPRs + one 32-bit VGPR offset (no per-lane 64-bit address math).
+// Issued from inline asm: the loads are NOT on hipcc's vmcnt scoreboard, so nothing may touch the
+// destination registers until the explicit vm_wait<0>() at the top of the next head (the two word sets
+// ping-pong, there is no register copy).
 template <int BITS>
 __device__ __forceinline__ void load_words(uint32_t (&w)[BITS], const uint32_t *__restrict__ mat,
-                                           int64_t row0, int64_t max_len, int64_t t) {
+                                           int64_t row0, int64_t max_len, uint32_t voff) {
 #pragma unroll
-  for (int i = 0; i < BITS; i++) w[i] = __builtin_nontemporal_load(mat + (row0 + i) * max_len + t);
+  for (int i = 0; i < BITS; i++) {
+    const uint32_t *base = mat + (row0 + i) * max_len;
+    asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(w[i]) : "v"(voff), "s"(base) : "memory");
+  }
 }
 
-constexpr int kSparseHpg = 16;   // heads per workgroup cap of the sparse variant (LDS budget)
+// byte `B` of x as a zero-extended dword, always ONE VALU instruction (hipcc otherwise splits the middle
+// bytes into shift + and)
+template <int B>
+__device__ __forceinline__ uint32_t byte_of(uint32_t x) {
+  uint32_t r;
+  if constexpr (B == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(r) : "v"(x));
+  else if constexpr (B == 3) asm("v_lshrrev_b32 %0, 24, %1" : "=v"(r) : "v"(x));
+  else asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(r) : "v"(x), "n"(8 * B));
+  return r;
+}
+
+constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse variant (LDS budget: 32 KB score tile)
+constexpr int kSparseChunks = 21;   // 64-entry chunks a wave holds at once: 32*n_out/64 = 21 at n_out = 42;
+                                    // wider rows take further rounds
 
 template <int BITS, bool SPARSE, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
+__global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
   constexpr int N = Fmt<BITS>::kN;
   constexpr int WPH = Fmt<BITS>::kWordsPerHead;
   constexpr int T = NWAVES * 32;
   constexpr int NT = NWAVES * 64;
   constexpr int TAB_B = KTab<BITS>::BUF_B;
-  constexpr int SC_B = SPARSE ? kSparseHpg * T * 4 : 16;
-  constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 16;
+  constexpr int SCS = kSparseHpg + 1;   // score-tile row stride (token-major, padded: see the sparse phase)
+  constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
+  constexpr int TAB_DMA = TAB_B / 1024;                        // 16-byte-per-lane DMA instructions per table
+  constexpr int TAB_DMA_W = (TAB_DMA + NWAVES - 1) / NWAVES;   // ... per wave
 
   // static LDS: every table offset below is a compile-time constant that folds into ds immediates
+  // q of the group's heads for the sparse phase: 16 KB.  With 4-bit tables it aliases table buffer 1, which
+  // is first written (by the DMA for the second head) after the sparse phase; smaller tables leave room.
+  constexpr bool QL_ALIAS = TAB_B >= kSparseHpg * kHeadDim * 4;
+  constexpr int QL_B = (SPARSE && !QL_ALIAS) ? kSparseHpg * kHeadDim * 4 : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TAB_B + 256 + SC_B + QL_B];
   unsigned char *lutq = smem;                                                    // [2][TAB_B]
   float *theta = reinterpret_cast<float *>(smem + 2 * TAB_B);                    // [64]
-  float *sc = reinterpret_cast<float *>(smem + 2 * TAB_B + 256);                 // [hpg][T]
-  float *ql = reinterpret_cast<float *>(smem + 2 * TAB_B + 256 + SC_B);          // [hpg][128]
+  float *sc = reinterpret_cast<float *>(smem + 2 * TAB_B + 256);                 // [T][SCS]
+  float *ql = reinterpret_cast<float *>(QL_ALIAS ? smem + TAB_B : smem + 2 * TAB_B + 256 + SC_B);   // [hpg][128]
+  const uint32_t lds0 = lds_addr(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = lane >> 5;
   const int tl = wave * 32 + (lane & 31);
   const int64_t tile0 = (int64_t)blockIdx.x * T;
@@ -119,20 +158,113 @@ __global__ __launch_bounds__(NWAVES * 64) void score_k_kernel(ScoreKArgs a, Rope
   const int h0 = blockIdx.y * a.hpg;
   const int b = blockIdx.z;
   const float *qb = a.q + (int64_t)b * a.H * kHeadDim;
+  const unsigned char *tabb = a.tab + ((int64_t)b * a.H + h0) * TAB_B;
 
+  // table of head `hh` -> LDS buffer `buf` (linear copy, lane*16 bytes per instruction)
+  auto issue_table = [&](int hh, int buf) {
+#pragma unroll
+    for (int k = 0; k < TAB_DMA_W; k++) {
+      const int j = wave + k * NWAVES;
+      if (j < TAB_DMA)
+        dma16(tabb + (int64_t)hh * TAB_B, (uint32_t)(j * 1024 + lane * 16), lds0 + buf * TAB_B + j * 1024);
+    }
+  };
+
+  // ---- sparse entries of the tile.  Wave w owns the 32 tokens it also decodes densely: a contiguous run
+  // of 32*n_out entries, walked in 64-lane chunks (fully coalesced, all lanes busy).  ALL chunk loads go
+  // out before anything else (kSparseChunks x 2 VGPRs; the 64 trig registers are not live yet), so the HBM
+  // latency is paid once per tile.
+  const bool do_sparse = SPARSE && b == 0 && a.outliers != nullptr;   // reference: batch 0 only (KCU:3605)
+  const int ntok = (a.L - tile0 < T) ? (int)(a.L - tile0) : T;
+  const unsigned nent = do_sparse ? (unsigned)ntok * (unsigned)a.n_out : 0u;   // entries of the tile
+  const unsigned wbase = (unsigned)wave * 32u * (unsigned)a.n_out;             // this wave's first entry
+  const unsigned wcnt = 32u * (unsigned)a.n_out;                               // ... and how many
+  const float *ov = a.outliers + tile0 * a.n_out;
+  const int32_t *oi = a.idx + tile0 * a.n_out;
+  constexpr int SPL = SPARSE ? kSparseChunks : 1;
+  float sv[SPL];
+  int si[SPL];
+  if constexpr (SPARSE) {
+    if (nent > 0) {   // wave-uniform; the loads themselves are unconditional (clamped index): a per-element
+                      // "load or zero" makes hipcc branch around every load and drain vmcnt each time
+#pragma unroll
+      for (int j = 0; j < SPL; j++) {
+        const unsigned e = wbase + j * 64 + lane;
+        const unsigned ec = e < nent ? e : nent - 1;
+        sv[j] = ov[ec];
+        si[j] = oi[ec];
+      }
+    }
+  }
+
+  issue_table(0, 0);
   if (tid < 64) theta[tid] = fr.f[tid];
   if constexpr (SPARSE) {
-    for (int i = tid; i < a.hpg * T; i += NT) sc[i] = 0.f;
+    for (int i = tid; i < T * SCS; i += NT) sc[i] = 0.f;
     for (int i = tid; i < a.hpg * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
   }
-  stage_lutq<BITS>(lutq, a.lut + (int64_t)h0 * kHeadDim * N, qb + h0 * kHeadDim, NT);
 
-  // first head's packed words (role r: channel groups r and 2+r)
-  uint32_t wlo[BITS], whi[BITS];
-  load_words<BITS>(wlo, a.mat, (int64_t)h0 * WPH + role * BITS, a.max_len, tc);
-  load_words<BITS>(whi, a.mat, (int64_t)h0 * WPH + (2 + role) * BITS, a.max_len, tc);
+  // packed words of the first head (role r: channel groups r and 2+r); the loop loads one head ahead
+  uint32_t wA_lo[BITS], wA_hi[BITS], wB_lo[BITS], wB_hi[BITS];   // even / odd head of the loop
+  // lane offset inside a head's rows: role r starts BITS rows further down (host checks it fits 32 bits)
+  const uint32_t woff = (uint32_t)(((int64_t)role * BITS * a.max_len + tc) * 4);
+  load_words<BITS>(wA_lo, a.mat, (int64_t)h0 * WPH, a.max_len, woff);
+  load_words<BITS>(wA_hi, a.mat, (int64_t)h0 * WPH + 2 * BITS, a.max_len, woff);
 
-  __syncthreads();
+  __syncthreads();   // theta / sc / ql visible
+
+  if constexpr (SPARSE) {
+    // The entries of a token are sorted by channel, so equal (token, head) keys are contiguous in the flat
+    // entry stream.  Per 64-entry chunk: every lane evaluates its entry, a 6-step segmented inclusive scan
+    // (wave shuffles) sums each run, and the run's LAST lane adds the sum into the LDS score tile with a
+    // plain read-modify-write: keys are distinct within a chunk and the wave owns its tokens, so no atomics
+    // (ds_add_f32 costs ~3 cycles per LANE on gfx950 and dominated this phase).
+    const int pos0 = (int)tile0 + a.pos_offset;
+    for (unsigned base = 0; base < wcnt && nent > 0; base += SPL * 64) {
+      if (base > 0) {   // rows wider than 42: further rounds (not on the nuq 1 % path)
+#pragma unroll
+        for (int j = 0; j < SPL; j++) {
+          const unsigned e = wbase + base + j * 64 + lane;
+          const unsigned ec = e < nent ? e : nent - 1;
+          sv[j] = ov[ec];
+          si[j] = oi[ec];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SPL; j++) {
+        const unsigned el = base + j * 64 + lane;          // entry within the wave's run
+        const unsigned e = wbase + el;
+        const bool in = (el < wcnt) && (e < nent);
+        const float val = sv[j];
+        const int col = si[j];
+        const int hh = (col >> 7) - h0;
+        // capped-away slot (zero, modeling_llama.py:745-747) or another head group: contributes nothing
+        const bool use = in && (val != 0.f) && ((unsigned)hh < (unsigned)a.hpg);
+        const unsigned tle = __umulhi(e, a.n_out_magic);   // token within the tile
+        const int ch = col & 127;
+        const float ang = theta[ch & 63] * (float)(pos0 + (int)tle);
+        float sn, c;
+        sincos_rev(ang, sn, c);
+        const int hq = use ? hh : 0;
+        const float q1 = ql[hq * kHeadDim + ch];
+        const float q2 = ql[hq * kHeadDim + ((ch + 64) & 127)];
+        const float sg = (ch < 64) ? sn : -sn;
+        float sum = use ? val * fmaf(c, q1, sg * q2) : 0.f;
+        // run key = (token, TRUE head): equal keys are contiguous because a token's entries are sorted by
+        // channel (a zeroed or foreign-group entry keeps its own head, it just carries 0)
+        const int key = in ? (int)(tle * 1024 + (unsigned)((col >> 7) & 1023)) : -1 - lane;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const float vu = __shfl_up(sum, d);
+          const int ku = __shfl_up(key, d);
+          if (lane >= d && ku == key) sum += vu;
+        }
+        const int kn = __shfl_down(key, 1);
+        const bool tail = (lane == 63) || (kn != key);
+        if (tail && in && sum != 0.f && (unsigned)hh < (unsigned)a.hpg) sc[tle * SCS + hh] += sum;
+      }
+    }
+  }
 
   // RoPE angles of this lane's token for its 32 rotation pairs (KCU:3083, 3122-3123)
   f32x2 cs[32];   // (cos, sin)
@@ -146,96 +278,92 @@ __global__ __launch_bounds__(NWAVES * 64) void score_k_kernel(ScoreKArgs a, Rope
     cs[i].y = sn;
   });
 
-  if constexpr (SPARSE) {
-    if (b == 0 && a.outliers != nullptr) {  // reference: sparse part ignores q_len > 1 (KCU:3605)
-      const int ntok = (a.L - tile0 < T) ? (int)(a.L - tile0) : T;
-      const unsigned nent = (unsigned)ntok * (unsigned)a.n_out;
-      const float *ov = a.outliers + tile0 * a.n_out;
-      const int32_t *oi = a.idx + tile0 * a.n_out;
-      const int pos0 = (int)tile0 + a.pos_offset;
-      for (unsigned e = tid; e < nent; e += NT) {
-        const float val = ov[e];
-        const int col = oi[e];
-        const int hh = (col >> 7) - h0;
-        if (val == 0.f || (unsigned)hh >= (unsigned)a.hpg) continue;   // capped-away slot / other head group
-        const unsigned tle = e / (unsigned)a.n_out;
-        const int ch = col & 127;
-        const float ang = theta[ch & 63] * (float)(pos0 + (int)tle);
-        float s, c;
-        sincos_rev(ang, s, c);
-        const float q1 = ql[hh * kHeadDim + ch];
-        const float q2 = ql[hh * kHeadDim + ((ch + 64) & 127)];
-        const float sg = (ch < 64) ? s : -s;
-        atomicAdd(&sc[hh * T + tle], val * fmaf(c, q1, sg * q2));
-      }
-    }
-  }
-
   // per-lane constant part of every look-up address
   const uint32_t rolepat = role ? 0x80808080u : 0u;     // 4 bit: role*128 in every byte
   const uint32_t rolebytes = (uint32_t)role * N * 8;    // generic
 
-  auto head = [&](auto BUF, int hh) {
+  auto head = [&](auto BUF, int hh, uint32_t (&wlo)[BITS], uint32_t (&whi)[BITS], uint32_t (&nlo)[BITS],
+                  uint32_t (&nhi)[BITS]) {
     constexpr int buf = decltype(BUF)::value;
     const int h = h0 + hh;
-    __syncthreads();  // table `buf` staged (and sc complete); the other table is free
-    uint32_t nlo[BITS], nhi[BITS];
-    if (hh + 1 < a.hpg) {
-      stage_lutq<BITS>(lutq + (1 - buf) * TAB_B, a.lut + (int64_t)(h + 1) * kHeadDim * N, qb + (h + 1) * kHeadDim, NT);
-      load_words<BITS>(nlo, a.mat, (int64_t)(h + 1) * WPH + role * BITS, a.max_len, tc);
-      load_words<BITS>(nhi, a.mat, (int64_t)(h + 1) * WPH + (2 + role) * BITS, a.max_len, tc);
+    // table `buf` and this head's words were issued one head ago
+    vm_wait<0>();
+    __syncthreads();  // ... landed for all waves (and sc complete); the other table is free
+    if (hh + 1 < a.hpg) issue_table(hh + 1, 1 - buf);
+    {
+      const int h1 = (hh + 1 < a.hpg) ? h + 1 : h;   // (re-reads a resident line past the last head)
+      load_words<BITS>(nlo, a.mat, (int64_t)h1 * WPH, a.max_len, woff);
+      load_words<BITS>(nhi, a.mat, (int64_t)h1 * WPH + 2 * BITS, a.max_len, woff);
     }
     const unsigned char *tlo = lutq + buf * TAB_B;
     const unsigned char *thi = lutq + buf * TAB_B + KTab<BITS>::HALF_B;
-    f32x2 acc = {0.f, 0.f};
+    // 16 look-ups (8 pairs) are issued back to back before their 16 packed FMAs, into 4 independent
+    // accumulators: the LDS pipe needs >= 16 reads in flight per wave to run at rate, and a single
+    // accumulator would serialise the FMAs
+    f32x2 acc4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         // even / odd nibbles as bytes = role*128 + code*8
         const uint32_t elo = ((wlo[j] << 3) & 0x78787878u) | rolepat, olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
         const uint32_t ehi = ((whi[j] << 3) & 0x78787878u) | rolepat, ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
-        static_for<0, 8>([&](auto NN) {
-          constexpr int n = decltype(NN)::value;
-          constexpr int i = 8 * j + n;
-          const uint32_t fl = (((n & 1) ? olo : elo) >> (8 * (n / 2))) & 0xffu;
-          const uint32_t fh = (((n & 1) ? ohi : ehi) >> (8 * (n / 2))) & 0xffu;
-          const f32x2 lo = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
-          const f32x2 hi = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
-          acc = __builtin_elementwise_fma(cs[i], lo, acc);
-          acc = __builtin_elementwise_fma(cs[i], hi, acc);
+        static_for<0, 2>([&](auto HH) {
+          constexpr int hf = decltype(HH)::value;   // two batches of 4 pairs = 8 look-ups each
+          f32x2 vl[4], vh[4];
+          static_for<0, 4>([&](auto NN) {
+            constexpr int n = 4 * hf + decltype(NN)::value;
+            constexpr int i = 8 * j + n;
+            const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
+            const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
+            vl[n & 3] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
+            vh[n & 3] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+          });
+          static_for<0, 4>([&](auto NN) {
+            constexpr int n = 4 * hf + decltype(NN)::value;
+            constexpr int i = 8 * j + n;
+            acc4[n & 3] = __builtin_elementwise_fma(cs[i], vl[n & 3], acc4[n & 3]);
+            acc4[(n + 2) & 3] = __builtin_elementwise_fma(cs[i], vh[n & 3], acc4[(n + 2) & 3]);
+          });
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // field extraction (VALU)
+          __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // 8 ds_read_b64
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // 8 v_pk_fma_f32
         });
       });
     } else {
-      static_for<0, 32>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const uint32_t fl = (code_of<BITS, i>(wlo) << 3) + rolebytes;
-        const uint32_t fh = (code_of<BITS, i>(whi) << 3) + rolebytes;
-        const f32x2 lo = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
-        const f32x2 hi = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
-        acc = __builtin_elementwise_fma(cs[i], lo, acc);
-        acc = __builtin_elementwise_fma(cs[i], hi, acc);
+      static_for<0, 4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        f32x2 vl[8], vh[8];
+        static_for<0, 8>([&](auto NN) {
+          constexpr int n = decltype(NN)::value;
+          constexpr int i = 8 * j + n;
+          const uint32_t fl = (code_of<BITS, i>(wlo) << 3) + rolebytes;
+          const uint32_t fh = (code_of<BITS, i>(whi) << 3) + rolebytes;
+          vl[n] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
+          vh[n] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+        });
+        static_for<0, 8>([&](auto NN) {
+          constexpr int n = decltype(NN)::value;
+          constexpr int i = 8 * j + n;
+          acc4[n & 3] = __builtin_elementwise_fma(cs[i], vl[n], acc4[n & 3]);
+          acc4[(n + 2) & 3] = __builtin_elementwise_fma(cs[i], vh[n], acc4[(n + 2) & 3]);
+        });
       });
     }
+    const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     float res = acc.x + acc.y;
     res += __shfl_xor(res, 32);
     if (role == 0 && valid) {
-      if constexpr (SPARSE) res += sc[hh * T + tl];
+      if constexpr (SPARSE) res += sc[tl * SCS + hh];
       float *dst = a.mul + ((int64_t)b * a.H + h) * a.L + t;
       if (a.accumulate) res += *dst;
-      *dst = res;
-    }
-    if (hh + 1 < a.hpg) {
-#pragma unroll
-      for (int i = 0; i < BITS; i++) {
-        wlo[i] = nlo[i];
-        whi[i] = nhi[i];
-      }
+      __builtin_nontemporal_store(res, dst);
     }
   };
   for (int hh = 0; hh < a.hpg; hh += 2) {
-    head(std::integral_constant<int, 0>{}, hh);
-    if (hh + 1 < a.hpg) head(std::integral_constant<int, 1>{}, hh + 1);
+    head(std::integral_constant<int, 0>{}, hh, wA_lo, wA_hi, wB_lo, wB_hi);
+    if (hh + 1 < a.hpg) head(std::integral_constant<int, 1>{}, hh + 1, wB_lo, wB_hi, wA_lo, wA_hi);
   }
+  vm_wait<0>();   // the look-ahead loads of the last head
 }
 
 // theta_j = powf(rope_theta, -2j/128) (KCU:3083): correctly rounded from double
@@ -275,7 +403,12 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
 }
 
 template <int BITS>
-static int dispatch_score(const ScoreKArgs &a, int q_len, float theta, bool sparse, hipStream_t st) {
+static int dispatch_score(ScoreKArgs a, const float *lut, void *ws, int q_len, float theta, bool sparse,
+                          hipStream_t st) {
+  lutq_prep_kernel<BITS><<<dim3(a.H, q_len), 256, 0, st>>>(lut, a.q, reinterpret_cast<unsigned char *>(ws), a.H);
+  int rc = check_launch();
+  if (rc) return rc;
+  a.tab = reinterpret_cast<const unsigned char *>(ws);
   // big tiles (8 waves) once there are enough of them, small tiles for short caches
   if (a.L >= 16384) {
     return sparse ? launch_score<BITS, true, 8>(a, q_len, theta, st) : launch_score<BITS, false, 8>(a, q_len, theta, st);
@@ -283,24 +416,39 @@ static int dispatch_score(const ScoreKArgs &a, int q_len, float theta, bool spar
   return sparse ? launch_score<BITS, true, 4>(a, q_len, theta, st) : launch_score<BITS, false, 4>(a, q_len, theta, st);
 }
 
+static size_t tab_bytes(int bits) {
+  return bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
+}
+
 }  // namespace kvq
 
 using namespace kvq;
 
-extern "C" int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul, const float *lut,
-                           int q_len, int H, int hd, int64_t L, int64_t max_len, float rope_theta,
-                           int pos_offset, const float *outliers, const int32_t *outlier_idx, int n_out,
-                           int accumulate, void *stream) {
-  if (!q || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 || L > max_len)
+extern "C" {
+
+size_t kvq_score_k_workspace_bytes(int bits, int q_len, int H) {
+  if (bits < 2 || bits > 4 || q_len <= 0 || H <= 0) return 0;
+  return (size_t)q_len * H * tab_bytes(bits);
+}
+
+int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul, const float *lut, int q_len, int H,
+                int hd, int64_t L, int64_t max_len, float rope_theta, int pos_offset, const float *outliers,
+                const int32_t *outlier_idx, int n_out, int accumulate, void *workspace, size_t workspace_bytes,
+                void *stream) {
+  if (!q || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 || L > max_len || bits < 2 ||
+      bits > 4)
     return KVQ_EINVAL;
   const bool sparse = outliers != nullptr;
-  if (sparse && (!outlier_idx || n_out <= 0)) return KVQ_EINVAL;
+  if (sparse && (!outlier_idx || n_out <= 0 || n_out > 4096)) return KVQ_EINVAL;
   if (L == 0) return KVQ_OK;
+  if (!workspace || workspace_bytes < kvq_score_k_workspace_bytes(bits, q_len, H) ||
+      reinterpret_cast<uintptr_t>(workspace) % 16)
+    return KVQ_EWORKSPACE;
   ScoreKArgs a;
   a.q = q;
   a.mat = reinterpret_cast<const uint32_t *>(mat);
   a.mul = mul;
-  a.lut = lut;
+  a.tab = nullptr;
   a.outliers = outliers;
   a.idx = outlier_idx;
   a.H = H;
@@ -309,12 +457,14 @@ extern "C" int kvq_score_k(int bits, const float *q, const int32_t *mat, float *
   a.max_len = max_len;
   a.pos_offset = pos_offset;
   a.n_out = n_out;
+  a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
   switch (bits) {
-    case 4: return dispatch_score<4>(a, q_len, rope_theta, sparse, st);
-    case 3: return dispatch_score<3>(a, q_len, rope_theta, sparse, st);
-    case 2: return dispatch_score<2>(a, q_len, rope_theta, sparse, st);
-    default: return KVQ_EINVAL;
+    case 4: return dispatch_score<4>(a, lut, workspace, q_len, rope_theta, sparse, st);
+    case 3: return dispatch_score<3>(a, lut, workspace, q_len, rope_theta, sparse, st);
+    default: return dispatch_score<2>(a, lut, workspace, q_len, rope_theta, sparse, st);
   }
 }
+
+}  // extern "C"

@@ -132,12 +132,14 @@ def score_k(bits, q, mat, mul, lut, L, theta, pos_offset, outliers=None, outlier
         raise ValueError("mul.shape[2] must equal kcachelen")
     n_out = 0 if outliers is None else outliers.shape[1]
     with _Dev(q):
+        nbytes = _L().kvq_score_k_workspace_bytes(bits, q.shape[0], H)
+        ws = _workspace(q.device, nbytes, slot="score")
         _lib.check(_L().kvq_score_k(
             bits, _f(q, "vec"), _i(mat, "mat"), _f(mul, "mul"), _f(lut, "lookup_table"), q.shape[0], H, hd,
             int(L), max_len, float(theta), int(pos_offset),
             None if outliers is None else _f(outliers, "outliers"),
             None if outliers is None else _i(outlier_indices, "outlier_indices"), n_out,
-            1 if accumulate else 0, _stream()), "kvq_score_k")
+            1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "kvq_score_k")
 
 
 def mix_v(bits, p, mat, mul, lut_rows, L, outliers=None, outlier_indices=None, accumulate=True):

@@ -37,7 +37,7 @@ def test_fused_decode_matches_oracle(gpu, bits, sinks):
     quant, scale, shift = _quantizer(bits, seed=bits)
     steps, max_len = 6, 16
     ks = util.k_tokens(steps, scale, shift, seed=10 + bits)
-    vs = util.v_tokens(steps, seed=20 + bits)
+    vs = util.v_tokens_no_ties(steps, seed=20 + bits)
     g = torch.Generator().manual_seed(bits)
     qs = torch.randn(steps, H, 1, HD, generator=g).half()
     kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,

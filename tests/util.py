@@ -43,6 +43,18 @@ def v_tokens(S, Cn=C, seed=2):
     return x.half().float()
 
 
+def v_tokens_no_ties(S, Cn=C, seed=2, k=21):
+    """like v_tokens but without ties at the k/(k+1) selection boundary of any token: torch.topk
+    leaves the choice among equal values unspecified (the GPU selection takes the lowest channel)."""
+    while True:
+        x = v_tokens(S, Cn, seed)
+        hi = torch.topk(x, k + 2, dim=-1).values
+        lo = torch.topk(x, k + 2, dim=-1, largest=False).values
+        if bool((hi[:, k - 1] != hi[:, k]).all() and (lo[:, k - 1] != lo[:, k]).all()):
+            return x
+        seed += 1000
+
+
 def rel_err(a, b, dim=-1):
     """max |a-b| relative to the max magnitude of the reference row"""
     a = a.double()
