@@ -15,7 +15,7 @@ H, HD, C = 32, 128, 4096
 def run(bits, L, sparse=True, iters=20, nrot=3):
     n = 2 ** bits
     W = HD // 32 * bits
-    max_len = L + 8
+    max_len = L + int(__import__("os").environ.get("KB_PAD", "8"))
     dev = torch.device("cuda")
     g = torch.Generator(device="cuda").manual_seed(0)
     mats = [torch.randint(-2 ** 31, 2 ** 31 - 1, (H, W, max_len), device=dev, dtype=torch.int64, generator=g).to(torch.int32)
