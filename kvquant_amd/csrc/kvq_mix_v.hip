@@ -60,9 +60,8 @@ struct VCfg {
   static constexpr int P_B = HW * CT * 4;
   static constexpr int QPL = QR / SLOTS;               // quads per lane per chunk
   static constexpr int BUF_B = TILE_B + LUT_B + P_B;   // one pipeline stage
-  static constexpr int SACC_B = UW * CH * 4;           // sparse accumulator
   static constexpr int RED_B = NT * CH * 4;            // slot reduction (aliases the stages)
-  static constexpr int SMEM_B = (2 * BUF_B > RED_B ? 2 * BUF_B : RED_B) + SACC_B;
+  static constexpr int SMEM_B = (2 * BUF_B > RED_B ? 2 * BUF_B : RED_B);
   static_assert(QR % SLOTS == 0, "slots must split the chunk's quads");
 };
 
@@ -73,6 +72,7 @@ struct MixArgs {
   const float *outliers;
   const int32_t *idx;
   float *partial;          // [n_ranges][q_len][C]
+  float *sparse_partial;   // [n_ranges*groups][C] (query row 0 only), or unused
   int H;
   int q_len;
   int64_t L;
@@ -81,6 +81,7 @@ struct MixArgs {
   int groups;              // unit groups (workgroups per range)
   int n_units;
   int n_out;
+  uint32_t n_out_magic;    // ceil(2^32 / n_out)
   int dbg;                 // development only: 1 = skip math, 2 = skip DMA
 };
 
@@ -188,7 +189,6 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
   constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT;
   __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B];  // static: LDS offsets fold into ds immediates
   unsigned char *stage0 = smem;
-  float *sacc = reinterpret_cast<float *>(smem + (Cfg::SMEM_B - Cfg::SACC_B));
 
   const int tid = threadIdx.x;
   const int ul = tid % Cfg::UW;          // unit within the workgroup
@@ -212,27 +212,69 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
   const uint32_t lds0 = lds_addr(smem);
   issue_chunk<BITS>(a, dl, lds0, t0, row_base, n_rows_valid, h0, b);
 
-  // ---- sparse residuals of this token range that fall in this group's channels
+  // ---- sparse residuals ------------------------------------------------------------------------------
+  // Workgroup (range, group g) takes the g-th share of the range's TOKENS for ALL channels, so every
+  // entry is touched once.  Sums are accumulated with 64-bit FIXED-POINT LDS atomics (2^-32 resolution,
+  // exact and order-independent): ds_add_u64 runs at ~0.1 cycle/lane on gfx950, ds_add_f32 at ~2.6
+  // (measured, tools/ubench/lds_atomic.hip).  The accumulator sits behind pipeline stage 0, idle until
+  // the first chunk iteration; the sums go to this workgroup's own sparse slab, which the reduce kernel
+  // adds like any other slab.
   const bool sparse = (a.outliers != nullptr) && (b == 0);   // reference: batch 0 only (KCU:3675)
-  if (a.outliers != nullptr) {
-    for (int i = tid; i < Cfg::UW * CH; i += Cfg::NT) sacc[i] = 0.f;
-  }
-  __syncthreads();
   if (sparse) {
-    const int ch0 = u0 * CH;
-    const float *ov = a.outliers + t0 * a.n_out;
-    const int32_t *oi = a.idx + t0 * a.n_out;
-    const float *p0 = a.p + t0;
-    const unsigned nent = (unsigned)(t1 - t0) * (unsigned)a.n_out;   // < 2^31: 32-bit index math
-    for (unsigned e = tid; e < nent; e += Cfg::NT) {
-      const int row = oi[e];
-      const unsigned rel = (unsigned)(row - ch0);
-      if (rel < (unsigned)(Cfg::UW * CH)) {
-        const float val = ov[e];
-        const unsigned tl = e / (unsigned)a.n_out;
-        const float pt = p0[(int64_t)(row >> 7) * a.L + tl];
-        atomicAdd(&sacc[rel], val * pt);
+    long long *sacc = reinterpret_cast<long long *>(smem + Cfg::BUF_B);
+    constexpr int SCH = (Cfg::SMEM_B - Cfg::BUF_B) / 8;       // channels per pass (>= 4096 for every format)
+    const int64_t share = ((t1 - t0) + a.groups - 1) / a.groups;
+    const int64_t s0 = t0 + (int64_t)g * share;
+    const int64_t s1 = (s0 + share < t1) ? (s0 + share) : t1;
+    const unsigned nent = s1 > s0 ? (unsigned)(s1 - s0) * (unsigned)a.n_out : 0u;   // < 2^31
+    const float *ov = a.outliers + s0 * a.n_out;
+    const int32_t *oi = a.idx + s0 * a.n_out;
+    const float *p0 = a.p + s0;
+    float *sslab = a.sparse_partial + (int64_t)blockIdx.x * C;
+    for (int c0 = 0; c0 < C; c0 += SCH) {
+      const int cn = (C - c0 < SCH) ? (C - c0) : SCH;
+      for (int i = tid; i < cn; i += Cfg::NT) sacc[i] = 0;
+      __syncthreads();
+      constexpr int RB = 21;   // entries per lane per round (a 256-token share at n_out = 42 in one round);
+                               // loads are unconditional (clamped index) and issued back to back
+      for (unsigned base = 0; base < nent; base += RB * Cfg::NT) {
+        int row[RB];
+        float val[RB];
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+          const unsigned e = base + j * Cfg::NT + tid;
+          const unsigned ec = e < nent ? e : nent - 1;
+          row[j] = oi[ec];
+          val[j] = ov[ec];
+        }
+        float pt[RB];
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+          const unsigned e = base + j * Cfg::NT + tid;
+          const unsigned ec = e < nent ? e : nent - 1;
+          const unsigned tl = __umulhi(ec, a.n_out_magic);
+          unsigned h = (unsigned)row[j] >> 7;
+          h = h < (unsigned)a.H ? h : (unsigned)a.H - 1u;
+          pt[j] = p0[(int64_t)h * a.L + tl];
+        }
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+          const unsigned e = base + j * Cfg::NT + tid;
+          const unsigned rel = (unsigned)(row[j] - c0);
+          if (e < nent && rel < (unsigned)cn) {
+            // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
+            const float x = val[j] * pt[j];
+            const float fl = floorf(x);
+            const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
+            const int hi = (int)fl;
+            const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sacc[rel]), fx);
+          }
+        }
       }
+      __syncthreads();
+      for (int i = tid; i < cn; i += Cfg::NT) sslab[c0 + i] = (float)((double)sacc[i] * (1.0 / 4294967296.0));
+      __syncthreads();   // (also frees the region for the pipeline / the next pass)
     }
   }
 
@@ -332,7 +374,6 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
       float s = red[(i * Cfg::SLOTS) * Cfg::UW + ul];
 #pragma unroll
       for (int k = 1; k < Cfg::SLOTS; k++) s += red[(i * Cfg::SLOTS + k) * Cfg::UW + ul];
-      if (a.outliers != nullptr) s += sacc[ul * CH + i];
       o[i] = s;
     }
 #pragma unroll
@@ -343,25 +384,29 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
 // mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  32 channels x 8 range lanes per block, 8
 // independent loads in flight per lane.
 __global__ __launch_bounds__(256) void mix_v_reduce_kernel(const float *__restrict__ partial,
-                                                           float *__restrict__ mul, int n_ranges, int q_len,
-                                                           int C, int accumulate) {
+                                                           const float *__restrict__ sparse_partial,
+                                                           float *__restrict__ mul, int n_ranges, int n_sparse,
+                                                           int q_len, int C, int accumulate) {
   __shared__ float red[8][32];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int b = blockIdx.y;
-  const int64_t stride = (int64_t)q_len * C;
   float s = 0.f;
   if (c < C) {
-    const float *src = partial + (int64_t)b * C + c;
-    int r = rg;
-    for (; r + 56 < n_ranges; r += 64) {
-      float v[8];
+    // dense slabs [r][b][c] and (query row 0 only) sparse slabs [k][c], 8 loads in flight per lane
+    auto run = [&](const float *src, int64_t stride, int n) {
+      int r = rg;
+      for (; r + 56 < n; r += 64) {
+        float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(r + 8 * k) * stride];
+        for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(r + 8 * k) * stride];
 #pragma unroll
-      for (int k = 0; k < 8; k++) s += v[k];
-    }
-    for (; r < n_ranges; r += 8) s += src[(int64_t)r * stride];
+        for (int k = 0; k < 8; k++) s += v[k];
+      }
+      for (; r < n; r += 8) s += src[(int64_t)r * stride];
+    };
+    run(partial + (int64_t)b * C + c, (int64_t)q_len * C, n_ranges);
+    if (b == 0 && n_sparse > 0) run(sparse_partial + c, C, n_sparse);
   }
   red[rg][cl] = s;
   __syncthreads();
@@ -393,7 +438,7 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   pl.tr = tr;
   pl.n_ranges = (int)((L + tr - 1) / tr);
   if (pl.n_ranges < 1) pl.n_ranges = 1;
-  pl.bytes = (size_t)pl.n_ranges * q_len * H * kHeadDim * sizeof(float);
+  pl.bytes = ((size_t)pl.n_ranges * q_len + (size_t)pl.n_ranges * pl.groups) * H * kHeadDim * sizeof(float);
   return pl;
 }
 
@@ -404,13 +449,15 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st) {
   a.tr = pl.tr;
   a.groups = pl.groups;
   a.n_units = pl.n_units;
+  a.sparse_partial = a.partial + (size_t)pl.n_ranges * a.q_len * a.H * kHeadDim;
   dim3 grid(pl.n_ranges * pl.groups, 1, a.q_len), block(Cfg::NT);
   mix_v_kernel<BITS><<<grid, block, 0, st>>>(a);
   int rc = check_launch();
   if (rc) return rc;
   const int C = a.H * kHeadDim;
   dim3 rgrid((C + 31) / 32, a.q_len);
-  mix_v_reduce_kernel<<<rgrid, 256, 0, st>>>(a.partial, mul, pl.n_ranges, a.q_len, C, accumulate);
+  mix_v_reduce_kernel<<<rgrid, 256, 0, st>>>(a.partial, a.sparse_partial, mul, pl.n_ranges,
+                                             a.outliers ? pl.n_ranges * pl.groups : 0, a.q_len, C, accumulate);
   return check_launch();
 }
 
@@ -480,6 +527,7 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
   a.outliers = outliers;
   a.idx = outlier_idx;
   a.partial = reinterpret_cast<float *>(workspace);
+  a.sparse_partial = nullptr;
   a.H = H;
   a.q_len = q_len;
   a.L = L;
@@ -488,6 +536,7 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
   a.groups = 1;
   a.n_units = 0;
   a.n_out = n_out;
+  a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.dbg = getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0;
   switch (bits) {
     case 4: return launch_mix<4>(a, mul, accumulate, st);
