@@ -1,0 +1,104 @@
+"""Layer-sharded KV cache across the GPUs of a node.
+
+The reference scales context by placing contiguous chunks of decoder layers --
+and therefore their compressed K/V caches -- on different GPUs
+(`LlamaModel.set_devices`, ML = modeling_llama.py:2428-2453) and moving the
+[1, q_len, hidden] activation with `.to("cuda:k")` at the split points
+(ML:2552-2556, 2583-2585) from ONE process.  Here: one process per GPU
+(`torch.distributed`; backend "nccl" is RCCL over xGMI on ROCm), rank r owns
+the layers the reference would put on cuda:r, and the activation (8 KB per hop
+at decode) travels by point-to-point send/recv over the direct xGMI link --
+there is no collective on the data path; a ring all-reduce of such a payload
+would only add latency.  This gives capacity scaling (1M tokens at nuq4 + 1 %
+= 5.07 GB per layer: 4 layers = 20 GB per GPU on 8 GPUs), not single-stream
+speed-up: the layers of one token are sequential.
+
+The per-layer work is injected as callables, so the routing logic is testable
+with the gloo backend on CPU (tests/test_sharding_cpu.py); on GPUs the callables
+are the MI355X layers built on `kvquant_amd.attention.KVQuantAttention`.
+"""
+import torch
+import torch.distributed as dist
+
+
+def layer_device(i, num_layers, world):
+    """device of layer i, exactly as ML:2444-2447: `min(world-1, i // (num_layers // world))`."""
+    if world <= 1:
+        return 0
+    nums = max(num_layers // world, 1)
+    return min(world - 1, i // nums)
+
+
+def layer_assignment(num_layers, world):
+    """list of owned layer indices per rank."""
+    out = [[] for _ in range(max(world, 1))]
+    for i in range(num_layers):
+        out[layer_device(i, num_layers, world)].append(i)
+    return out
+
+
+def split_indices(num_layers, world):
+    """layer indices at which the activation changes device (ML:2443-2449)."""
+    return [i for i in range(1, num_layers) if layer_device(i, num_layers, world) != layer_device(i - 1, num_layers, world)]
+
+
+def kv_bytes_per_layer(bits, tokens, hidden=4096, n_out=42):
+    """resident bytes of one layer's K+V cache at `tokens` cached tokens."""
+    dense = hidden * bits // 8
+    return tokens * (2 * dense + 2 * n_out * 8 + 4 * 2 ** bits)
+
+
+class LayerShardedPipeline:
+    """Runs `layers` (callables hidden -> hidden; only the ones this rank owns are called) as the
+    reference's sequential layer pipeline over `world` ranks.
+
+    step(hidden): rank 0 passes the input; every rank returns the final hidden state of the LAST
+    layer on rank 0 (ML:2583-2585 moves it back for norm / lm_head) and None elsewhere.
+    """
+
+    def __init__(self, layers, rank=None, world=None, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.num_layers = len(layers)
+        self.owned = layer_assignment(self.num_layers, self.world)[self.rank]
+        self.layers = layers
+        # ranks that actually own layers, in pipeline order
+        self.active = [r for r, ls in enumerate(layer_assignment(self.num_layers, self.world)) if ls]
+
+    def _prev_next(self):
+        k = self.active.index(self.rank) if self.rank in self.active else -1
+        prev_r = self.active[k - 1] if k > 0 else None
+        next_r = self.active[k + 1] if 0 <= k < len(self.active) - 1 else None
+        return k, prev_r, next_r
+
+    def step(self, hidden, template=None):
+        """hidden: the input activation on the first active rank (ignored elsewhere);
+        template: a tensor giving shape/dtype/device for receives on the other ranks."""
+        if self.world == 1:
+            for i in self.owned:
+                hidden = self.layers[i](hidden)
+            return hidden
+        k, prev_r, next_r = self._prev_next()
+        first, last = self.active[0], self.active[-1]
+        buf = None
+        if k >= 0:
+            if prev_r is None:
+                buf = hidden
+            else:
+                buf = torch.empty_like(template if template is not None else hidden)
+                dist.recv(buf, src=prev_r, group=self.group)
+            for i in self.owned:
+                buf = self.layers[i](buf)
+            if next_r is not None:
+                dist.send(buf.contiguous(), dst=next_r, group=self.group)
+        # final activation back to the first rank
+        if last != first:
+            if self.rank == last:
+                dist.send(buf.contiguous(), dst=first, group=self.group)
+            elif self.rank == first:
+                out = torch.empty_like(template if template is not None else hidden)
+                dist.recv(out, src=last, group=self.group)
+                return out
+            return None
+        return buf if self.rank == first else None

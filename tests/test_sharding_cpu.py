@@ -1,0 +1,76 @@
+"""CPU (gloo, world_size 2 and 3): the layer-sharded pipeline routes activations exactly like
+the reference's set_devices placement (modeling_llama.py:2428-2453, 2552-2556, 2583-2585)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kvquant_amd import sharding
+
+
+def test_assignment_matches_reference_rule():
+    # 32 layers on 8 GPUs: 4 contiguous layers each (DL:171 -> ML:2428)
+    a = sharding.layer_assignment(32, 8)
+    assert a == [list(range(4 * r, 4 * r + 4)) for r in range(8)]
+    assert sharding.split_indices(32, 8) == [4, 8, 12, 16, 20, 24, 28]
+    # remainder layers pile up on the last device, as `min(n-1, i // nums)` does
+    a = sharding.layer_assignment(10, 4)
+    assert a == [[0, 1], [2, 3], [4, 5], [6, 7, 8, 9]]
+    assert sharding.layer_assignment(5, 1) == [[0, 1, 2, 3, 4]]
+    # 1M tokens nuq4 + 1 %: 5.07 GB per layer
+    assert abs(sharding.kv_bytes_per_layer(4, 1 << 20) / 1e9 - 5.07) < 0.03
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_layers, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    called = []
+
+    def make(i):
+        def f(x):
+            called.append(i)
+            return x * 1.5 + float(i)        # order-sensitive
+        return f
+    layers = [make(i) for i in range(n_layers)]
+    pipe = sharding.LayerShardedPipeline(layers)
+    x0 = torch.arange(8, dtype=torch.float32).view(1, 1, 8)
+    outs = []
+    for step in range(3):
+        y = pipe.step(x0 + step, template=x0)
+        outs.append(None if y is None else y.clone())
+    ret[rank] = (called, outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_layers", [(2, 6), (3, 7)])
+def test_pipeline_over_gloo(world, n_layers):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_layers, ret), nprocs=world, join=True)
+    x0 = torch.arange(8, dtype=torch.float32).view(1, 1, 8)
+    owned = sharding.layer_assignment(n_layers, world)
+    for r in range(world):
+        called, outs = ret[r]
+        assert called == owned[r] * 3, (r, called)          # only its own layers, in order, every step
+        for step in range(3):
+            if r == 0:
+                ref = x0 + step
+                for i in range(n_layers):
+                    ref = ref * 1.5 + float(i)
+                assert torch.equal(outs[step], ref)
+            else:
+                assert outs[step] is None
