@@ -167,6 +167,33 @@ KVQ_API int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores,
                       int n_sink, float inv_sqrt_hd, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* ---- uncapped ("orig") Dense-and-Sparse variants, 4 bit only ------------------ */
+
+/* VecQuant4AppendVecKSparseOrig + ...2Orig (KCU:691-931): outlier iff x<lo || x>hi ->
+ * code 7 and a sparse entry (channel, x - zeropoint[c]) in ascending channel order;
+ * out_idx / out_val need room for H*hd entries; *out_count (device) = number written.
+ * Growing the CSR arrays is left to the caller, as in the reference's host code. */
+KVQ_API int kvq_append_k_sparse_orig(int32_t *mat, const float *lut, const float *x,
+                             const float *zeropoint, const float *lo, const float *hi,
+                             int32_t *out_idx, float *out_val, int32_t *out_count,
+                             int H, int hd, int64_t max_len, int64_t col, void *stream);
+/* VecQuant4AppendVecVSparseOrig (KCU:933-1163): scalar thresholds / zero point,
+ * per-token codebook row lut_rows[col]. */
+KVQ_API int kvq_append_v_sparse_orig(int32_t *mat, const float *lut_rows, const float *x,
+                             float zeropoint, float lo, float hi, int32_t *out_idx,
+                             float *out_val, int32_t *out_count, int H, int hd,
+                             int64_t max_len, int64_t col, void *stream);
+/* SPMV_ATOMIC_CSR_ROPE_BALANCED (KCU:524-614): mul[head][t] += sum over the CSR row t
+ * (rowptr[num_rows+1], cols = global channel) of val * RoPE-weighted q; q row 0 only. */
+KVQ_API int kvq_spmv_k_rope_csr(const int32_t *rowptr, const int32_t *cols, const float *vals,
+                        const float *q, float *mul, int64_t num_rows, int64_t L, int hd,
+                        float rope_theta, int pos_offset, void *stream);
+/* SPMV_ATOMIC_CSC_BALANCED (KCU:617-689): mul[row] += val * p[row/128][t] over the CSC
+ * column t (colptr[num_cols+1]). */
+KVQ_API int kvq_spmv_v_csc(const int32_t *colptr, const int32_t *rows, const float *vals,
+                   const float *p, float *mul, int64_t num_cols, int64_t L, int H,
+                   int hd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

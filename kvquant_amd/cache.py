@@ -46,8 +46,8 @@ class QuantK(nn.Module):
         super().__init__()
         if bits not in (2, 3, 4):
             raise ValueError("bits must be 2, 3 or 4")
-        if use_orig_sparse:
-            raise NotImplementedError("use_orig_sparse (uncapped CSR outliers) is not built yet")
+        if use_orig_sparse and bits != 4:
+            raise ValueError("use_orig_sparse is 4-bit only (as the reference, ML:513)")
         self.hidden_size = hidden_size
         self.num_heads = num_heads
         self.head_dim = hidden_size // num_heads
@@ -74,10 +74,20 @@ class QuantK(nn.Module):
         self.first_few_fp16 = first_few_fp16
         self.norm = False
         self.lookup_table2 = None
+        self._reset_csr(dev)
 
     @property
     def device(self):
         return self.kcache.device
+
+    def _reset_csr(self, dev):
+        # uncapped-outlier CSR state (ML:402-408)
+        self.rows = torch.tensor([], device=dev)
+        self.cols = torch.tensor([], device=dev)
+        self.vals = torch.tensor([], device=dev)
+        self.start_rows = torch.tensor([], device=dev)
+        self.num_threads = -1
+        self.num_nonzeros = 0
 
     def reset(self):
         """ML:416-434 (plain zero fill instead of a masked assignment)."""
@@ -86,6 +96,7 @@ class QuantK(nn.Module):
         if self.include_sparse:
             self.outliers.zero_()
             self.outlier_indices.zero_()
+            self._reset_csr(self.device)
 
     def load_lookup_table(self, quantizer, include_sparse=True, sparsity_threshold=0.99, norm=False):
         """ML:437-501.  thresholds -> fp16; offset / range formed in fp16;
@@ -188,6 +199,63 @@ class QuantK(nn.Module):
         self.outliers[col0:col0 + S] = vals
         self.outlier_indices[col0:col0 + S] = idx
 
+
+    # ---- uncapped outliers (use_orig_sparse=True), 4 bit only ---------------------------------------
+    def forward_fused_sparse_orig(self, q, k):
+        """ML:504-559: outliers = everything outside the thresholds (code 7, residual x - zeropoint) kept
+        in a growing CSR matrix; dense scores + CSR SpMV."""
+        assert self.include_sparse and self.bits == 4
+        from . import quant_cuda as qc
+        k = k.flatten().float().contiguous()
+        q = q.float().transpose(0, 1).contiguous()
+        pos = self.klen - self.first_few_fp16
+        self.rows, self.cols, self.vals, self.start_rows, nt, _ = qc.vecquant4appendvecKsparseorig(
+            self.kcache, self.lookup_table, k, self.zeropoint, self.rows, self.cols, self.vals, self.start_rows,
+            self.outlier_threshold_lower, self.outlier_threshold_upper, pos)
+        self.num_threads = int(nt[0])
+        self.num_nonzeros = self.vals.shape[0]
+        self.klen += 1
+        L = self.klen - self.first_few_fp16
+        mul = torch.zeros((q.shape[0], q.shape[1], L), dtype=torch.float32, device=q.device)
+        qc.vecquant4matmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt2_orig(
+            q, self.kcache, mul, self.lookup_table, L, self.rows, self.cols, self.start_rows, self.vals, L,
+            self.num_threads, self.num_nonzeros, self.rope_theta, self.first_few_fp16)
+        return mul.transpose(0, 1).contiguous().half()
+
+    def parallel_pack_orig(self, k):
+        """ML:563-649.  NOTE (reference quirk, replicated): prefill packs with the CAPPED kernel (outliers
+        saturate to the end codes) and stores residuals to the END codebook values, while decode forces
+        code 7 and stores x - zeropoint."""
+        assert self.include_sparse and self.bits == 4
+        k = k.float().contiguous()
+        S = k.shape[-1]
+        self.klen += S
+        resc = torch.empty_like(k)
+        ops.pack_k_sparse_parallel(4, self.kcache, self.lookup_table, k, resc, self.outlier_threshold_lower,
+                                   self.outlier_threshold_upper, 0)
+        k = k.reshape(-1, S).clone()
+        lower = k < self.outlier_threshold_lower.unsqueeze(-1)
+        above = k > self.outlier_threshold_upper.unsqueeze(-1)
+        lut = self.lookup_table.reshape(-1, 16)
+        k1 = k - lut[:, 0].unsqueeze(-1)
+        k2 = k - lut[:, 15].unsqueeze(-1)
+        k[lower] = k1[lower]
+        k[above] = k2[above]
+        k[~torch.logical_or(above, lower)] = 0
+        csr = k.t().contiguous().to_sparse_csr()
+        self.rows = csr.crow_indices().int()
+        self.cols = csr.col_indices().int()
+        self.vals = csr.values().float()
+        if len(self.vals) > 0:
+            self.num_threads = int((self.vals.shape[0] + 9) / 10)
+            self.num_nonzeros = self.vals.shape[0]
+            nt_pad = int((self.num_threads + 127) / 128) * 128
+            # start row of every 10-nnz thread (ML:638-646), vectorised: first row whose end exceeds j*10
+            ends = self.rows[1:].long()
+            j10 = torch.arange(nt_pad, device=k.device) * 10
+            start = torch.searchsorted(ends, j10, right=True).int()
+            start[j10 >= ends[-1]] = -1
+            self.start_rows = start
 
 class QuantV(nn.Module):
     """Compressed value cache with per-token codebooks (ML:978-1385)."""

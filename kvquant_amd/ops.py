@@ -204,3 +204,77 @@ def softmax_scale(scores, inv_sqrt_hd, sink_scores=None):
             _f(probs, "probs"), None if sink_probs is None else sink_probs.data_ptr(), H, L, n_sink,
             float(inv_sqrt_hd), ws.data_ptr(), ws.numel(), _stream()), "kvq_softmax_scale")
     return probs, sink_probs
+
+
+# ---- uncapped ("orig") CSR / CSC variants, 4 bit --------------------------------------------------
+def _grow(ptr, minor, val, start, idx, v, pos):
+    """the reference's host-side CSR/CSC growth (KCU:763-829, 1010-1060) on device tensors"""
+    dev = idx.device
+    cnt = idx.numel()
+    if ptr.numel() == 0:
+        ptr2 = torch.tensor([0, cnt], dtype=torch.int32, device=dev)
+        minor2, val2 = idx, v
+        nt = (cnt + 9) // 10
+        start2 = torch.full((nt,), pos, dtype=torch.int32, device=dev)
+    else:
+        ptr2 = torch.cat((ptr.int(), torch.tensor([minor.numel() + cnt], dtype=torch.int32, device=dev)))
+        if cnt > 0:
+            minor2 = torch.cat((minor.int(), idx))
+            val2 = torch.cat((val.float(), v))
+            nt = (minor2.numel() + 9) // 10
+            new_alloc = nt - start.numel()
+            start2 = torch.cat((start.int(), torch.full((new_alloc,), pos, dtype=torch.int32, device=dev))) \
+                if new_alloc > 0 else start
+        else:
+            minor2, val2, start2 = minor, val, start
+            nt = (minor2.numel() + 9) // 10
+    return ptr2, minor2, val2, start2, nt
+
+
+def _append_orig(is_v, mat, lut, x, zeropoint, lo, hi, col):
+    H, hd, max_len = _cache_dims(mat, 4)
+    C = H * hd
+    oi = torch.empty(C, dtype=torch.int32, device=mat.device)
+    ov = torch.empty(C, dtype=torch.float32, device=mat.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=mat.device)
+    with _Dev(mat):
+        if is_v:
+            _lib.check(_L().kvq_append_v_sparse_orig(_i(mat, "mat"), _f(lut, "lookup_table"), _f(x, "newvec"),
+                                                     float(zeropoint), float(lo), float(hi), oi.data_ptr(),
+                                                     ov.data_ptr(), cnt.data_ptr(), H, hd, max_len, int(col),
+                                                     _stream()), "kvq_append_v_sparse_orig")
+        else:
+            _lib.check(_L().kvq_append_k_sparse_orig(_i(mat, "mat"), _f(lut, "lookup_table"), _f(x, "newvec"),
+                                                     _f(zeropoint, "zeropoint"), _f(lo, "lower"), _f(hi, "upper"),
+                                                     oi.data_ptr(), ov.data_ptr(), cnt.data_ptr(), H, hd, max_len,
+                                                     int(col), _stream()), "kvq_append_k_sparse_orig")
+    n = int(cnt.item())          # the reference synchronises here too (KCU:745-747)
+    return oi[:n].clone(), ov[:n].clone(), cnt
+
+
+def append_k_sparse_orig(mat, lut, x, zeropoint, row, col, val, start_rows, lo, hi, kcachelen):
+    idx, v, cnt = _append_orig(False, mat, lut, x, zeropoint, lo, hi, kcachelen)
+    rows, cols, vals, start, nt = _grow(row, col, val, start_rows, idx, v, kcachelen)
+    return [rows, cols, vals, start, torch.tensor([nt], dtype=torch.int32), cnt]
+
+
+def append_v_sparse_orig(mat, lut_rows, x, zeropoint, row, col, val, start_cols, lo, hi, vcachelen):
+    idx, v, cnt = _append_orig(True, mat, lut_rows, x, zeropoint, lo, hi, vcachelen)
+    cols, rows, vals, start, nt = _grow(col, row, val, start_cols, idx, v, vcachelen)
+    return [rows, cols, vals, start, torch.tensor([nt], dtype=torch.int32), cnt]
+
+
+def spmv_k_rope_csr(rowptr, cols, vals, q, mul, num_rows, L, theta, pos_offset):
+    with _Dev(q):
+        _lib.check(_L().kvq_spmv_k_rope_csr(_i(rowptr, "rows"), _i(cols, "cols") if cols.numel() else None,
+                                            _f(vals, "vals") if vals.numel() else None, _f(q, "vec"), _f(mul, "mul"),
+                                            int(num_rows), int(L), q.shape[2], float(theta), int(pos_offset),
+                                            _stream()), "kvq_spmv_k_rope_csr")
+
+
+def spmv_v_csc(colptr, rows, vals, p, mul, num_cols, L):
+    H, hd = mul.shape[1], mul.shape[2]
+    with _Dev(p):
+        _lib.check(_L().kvq_spmv_v_csc(_i(colptr, "cols"), _i(rows, "rows") if rows.numel() else None,
+                                       _f(vals, "vals") if vals.numel() else None, _f(p, "vec"), _f(mul, "mul"),
+                                       int(num_cols), int(L), H, hd, _stream()), "kvq_spmv_v_csc")

@@ -70,4 +70,43 @@ def _make(bits):
 _NS = {}
 for _b in (2, 3, 4):
     _NS.update(_make(_b))
+
+
+# ---- the four uncapped ("orig") entry points, 4 bit only (KCPP:381-399, 432-435) -------------------
+def vecquant4appendvecKsparseorig(mat, lookup_table, newvec, zeropoint, row, col, val, start_rows,
+                                  outlier_threshold_lower, outlier_threshold_upper, kcachelen):
+    return ops.append_k_sparse_orig(mat, lookup_table, newvec, zeropoint, row, col, val, start_rows,
+                                    outlier_threshold_lower, outlier_threshold_upper, kcachelen)
+
+
+def vecquant4appendvecVsparseorig(mat, lookup_table, newvec, zeropoint, row, col, val, start_cols,
+                                  outlier_threshold_lower, outlier_threshold_upper, vcachelen):
+    return ops.append_v_sparse_orig(mat, lookup_table, newvec, zeropoint, row, col, val, start_cols,
+                                    outlier_threshold_lower, outlier_threshold_upper, vcachelen)
+
+
+def vecquant4matmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt2_orig(
+        vec, mat, mul, lookup_table, kcachelen, rows, cols, startrows, spmat, num_rows, num_threads, nnz,
+        rope_theta, pos_offset):
+    """dense q.K^T then the CSR SpMV (KCU:5506-5596); startrows / num_threads only balance the
+    reference's threads and do not enter the result."""
+    ops.score_k(4, vec, mat, mul, lookup_table, kcachelen, rope_theta, pos_offset)
+    if int(nnz) > 0:
+        ops.spmv_k_rope_csr(rows.int().contiguous(), cols.int().contiguous(), spmat, vec, mul, num_rows,
+                            kcachelen, rope_theta, pos_offset)
+
+
+def vecquant4matmul_nuq_perchannel_transposed_mha_batched_fused_opt2_orig(
+        vec, mat, mul, lookup_table, vcachelen, rows, cols, startcols, spmat, num_rows, num_threads, nnz):
+    ops.mix_v(4, vec, mat, mul, lookup_table, vcachelen)
+    if int(nnz) > 0:
+        ops.spmv_v_csc(cols.int().contiguous(), rows.int().contiguous(), spmat, vec, mul, num_rows, vcachelen)
+
+
+_NS["vecquant4appendvecKsparseorig"] = vecquant4appendvecKsparseorig
+_NS["vecquant4appendvecVsparseorig"] = vecquant4appendvecVsparseorig
+_NS["vecquant4matmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt2_orig"] = \
+    vecquant4matmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt2_orig
+_NS["vecquant4matmul_nuq_perchannel_transposed_mha_batched_fused_opt2_orig"] = \
+    vecquant4matmul_nuq_perchannel_transposed_mha_batched_fused_opt2_orig
 globals().update(_NS)

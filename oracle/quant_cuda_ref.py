@@ -69,49 +69,45 @@ for _b in (2, 3, 4):
 
 
 # ---- uncapped CSR/CSC ("orig") variants, 4-bit only ---------------------
-def _start_rows(ptr, num_threads, nnz):
-    """start row of every balanced thread (reference: KCU:797-823).  Thread i
-    starts at nnz index i*per; its start row is the row containing it, or -1
-    past the end."""
-    per = (nnz + num_threads - 1) // num_threads if num_threads > 0 else 0
-    out = torch.full((max(num_threads, 1),), -1, dtype=torch.int32)
-    for i in range(num_threads):
-        s = i * per
-        if s < nnz:
-            out[i] = int(torch.searchsorted(ptr, torch.tensor(s, dtype=ptr.dtype), right=True)) - 1
-    return out
+def _grow(ptr, minor, val, start, idx, v, pos):
+    """CSR/CSC growth of KCU:763-829 (K) / 1010-1060 (V): `ptr` gains one entry (running nnz),
+    `minor`/`val` gain the new entries, `start` gains `pos` for every newly needed 10-nnz thread."""
+    cnt = idx.numel()
+    if ptr.numel() == 0:
+        ptr2 = torch.tensor([0, cnt], dtype=torch.int32)
+        minor2, val2 = idx, v
+        nt = (cnt + 9) // 10
+        start2 = torch.full((nt,), pos, dtype=torch.int32)
+    else:
+        ptr2 = torch.cat((ptr.int(), torch.tensor([minor.numel() + cnt], dtype=torch.int32)))
+        if cnt > 0:
+            minor2 = torch.cat((minor.int(), idx))
+            val2 = torch.cat((val.float(), v))
+            nt = (minor2.numel() + 9) // 10
+            new_alloc = nt - start.numel()
+            start2 = torch.cat((start.int(), torch.full((new_alloc,), pos, dtype=torch.int32))) if new_alloc > 0 else start
+        else:
+            minor2, val2, start2 = minor, val, start
+            nt = (minor2.numel() + 9) // 10
+    return ptr2, minor2, val2, start2, nt
 
 
 def vecquant4appendvecKsparseorig(mat, lookup_table, newvec, zeropoint, row, col, val, start_rows,
                                   lo, hi, kcachelen):
-    """Returns [rows(ptr), cols, vals, start_rows, num_threads(cpu int[1]), outlier_count]
-    like KCU:691-830: the CSR arrays grow by concatenation; 10 nnz per thread."""
+    """returns [rows(ptr), cols, vals, start_rows, num_threads(cpu int[1]), outlier_count] (KCU:691-830)"""
     idx, v = ck.append_k_sparse_orig(mat, lookup_table, newvec, zeropoint, lo, hi, kcachelen)
-    if row.numel() == 0:
-        row = torch.zeros(1, dtype=torch.int32)
-    rows = torch.cat((row.int(), (row[-1:].int() + idx.numel())))
-    cols = torch.cat((col.int(), idx))
-    vals = torch.cat((val.float(), v))
-    nnz = int(rows[-1])
-    num_threads = (nnz + 9) // 10
-    start = _start_rows(rows, num_threads, nnz)
-    return [rows, cols, vals, start, torch.tensor([num_threads], dtype=torch.int32),
+    rows, cols, vals, start, nt = _grow(row, col, val, start_rows, idx, v, kcachelen)
+    return [rows, cols, vals, start, torch.tensor([nt], dtype=torch.int32),
             torch.tensor([idx.numel()], dtype=torch.int32)]
 
 
 def vecquant4appendvecVsparseorig(mat, lookup_table, newvec, zeropoint, row, col, val, start_cols,
                                   lo, hi, vcachelen):
+    """returns [rows, cols(ptr), vals, start_cols, num_threads, outlier_count] (KCU:933-1066)"""
     idx, v = ck.append_v_sparse_orig(mat, lookup_table, newvec, float(zeropoint), float(lo), float(hi),
                                      vcachelen)
-    if col.numel() == 0:
-        col = torch.zeros(1, dtype=torch.int32)
-    cols = torch.cat((col.int(), (col[-1:].int() + idx.numel())))
-    rows = torch.cat((row.int(), idx))
-    vals = torch.cat((val.float(), v))
-    nnz = int(cols[-1])
-    num_threads = (nnz + 9) // 10
-    start = _start_rows(cols, num_threads, nnz)
-    return [rows, cols, vals, start, torch.tensor([num_threads], dtype=torch.int32),
+    cols, rows, vals, start, nt = _grow(col, row, val, start_cols, idx, v, vcachelen)
+    return [rows, cols, vals, start, torch.tensor([nt], dtype=torch.int32),
             torch.tensor([idx.numel()], dtype=torch.int32)]
 
 

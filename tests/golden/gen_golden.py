@@ -83,7 +83,7 @@ def quantizer_for(k_calib, bits):
     return (upper, lower, [nf_centroids(bits)])
 
 
-def run_scenario(QuantK, QuantV, name, bits, include_sparse, sinks, S, steps, seed):
+def run_scenario(QuantK, QuantV, name, bits, include_sparse, sinks, S, steps, seed, orig=False):
     max_len = S + steps + sinks + 3
     T = S + steps
     # torch.topk leaves the choice among EQUAL values unspecified; keep the fixtures free of ties at
@@ -102,13 +102,14 @@ def run_scenario(QuantK, QuantV, name, bits, include_sparse, sinks, S, steps, se
 
     kc = QuantK(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
                 include_sparse=include_sparse, sparsity_threshold=0.99, rope_theta=THETA,
-                first_few_fp16=sinks)
+                first_few_fp16=sinks, use_orig_sparse=orig)
     vc = QuantV(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
                 include_sparse=include_sparse, sparsity_threshold=0.99, first_few_fp16=sinks)
     kc.load_lookup_table(quant, include_sparse=include_sparse, sparsity_threshold=0.99)
     vc.load_lookup_table(quant, include_sparse=include_sparse, sparsity_threshold=0.99)
 
     out = {"bits": bits, "include_sparse": int(include_sparse), "sinks": sinks, "S": S, "steps": steps,
+           "orig": int(orig),
            "max_len": max_len, "theta": THETA,
            "q_upper": quant[0].astype(np.float32), "q_lower": quant[1].astype(np.float32),
            "q_centroids": quant[2][0],
@@ -123,7 +124,10 @@ def run_scenario(QuantK, QuantV, name, bits, include_sparse, sinks, S, steps, se
     if include_sparse and S > 0:
         ks = k_all[sinks:sinks + S].view(S, H, HD).permute(1, 2, 0)      # [H, hd, S] like ML:1913
         vs = v_all[sinks:sinks + S].view(S, H, HD).permute(1, 2, 0)
-        kc.parallel_pack(ks)
+        if orig:
+            kc.parallel_pack_orig(ks)                                    # ML:1886-1887
+        else:
+            kc.parallel_pack(ks)
         kc.klen += sinks                                                 # ML:1890
         vflat = v_all[sinks:sinks + S].float()
         uv, ui = torch.topk(vflat, thr, dim=-1)                          # ML:1556-1557
@@ -139,7 +143,7 @@ def run_scenario(QuantK, QuantV, name, bits, include_sparse, sinks, S, steps, se
         t = sinks + S + i
         q = q_all[t].view(H, 1, HD)                                      # already "post-RoPE"
         k = k_all[t].view(1, H, 1, HD)
-        scores = kc.forward_fused_sparse(q, k)                           # [H,1,L] half
+        scores = kc.forward_fused_sparse_orig(q, k) if orig else kc.forward_fused_sparse(q, k)   # [H,1,L] half
         out["score_%d" % i] = scores.numpy().copy()
         aw = (scores.unsqueeze(0) / math.sqrt(HD))                       # ML:1972-1973 (fp16)
         aw = torch.softmax(aw, dim=-1, dtype=torch.float32).to(torch.float16).squeeze(0)
@@ -159,7 +163,13 @@ def run_scenario(QuantK, QuantV, name, bits, include_sparse, sinks, S, steps, se
     out["kcache"] = kc.kcache[:, :, :L].numpy().copy()
     out["vcache"] = vc.vcache[:, :, :L].numpy().copy()
     out["v_lookup_table"] = vc.lookup_table[:L].numpy().copy()
-    if include_sparse:
+    if orig:
+        out["k_rows"] = kc.rows.numpy().copy()
+        out["k_cols"] = kc.cols.numpy().copy()
+        out["k_vals"] = kc.vals.numpy().copy()
+        out["k_start_rows"] = kc.start_rows.numpy().copy()
+        out["k_num_threads"] = int(kc.num_threads)
+    elif include_sparse:
         out["k_outliers"] = kc.outliers[:L].numpy().copy()
         out["k_outlier_indices"] = kc.outlier_indices[:L].numpy().copy()
         out["v_outliers"] = vc.outliers[:L].numpy().copy()
@@ -175,6 +185,7 @@ def main():
     run_scenario(QuantK, QuantV, "ref_nuq3_sparse_sink5", 3, True, 5, 6, 2, seed=3)
     run_scenario(QuantK, QuantV, "ref_nuq2_sparse", 2, True, 0, 5, 2, seed=2)
     run_scenario(QuantK, QuantV, "ref_nuq4_dense", 4, False, 0, 0, 3, seed=14)
+    run_scenario(QuantK, QuantV, "ref_nuq4_orig", 4, True, 0, 5, 3, seed=24, orig=True)
 
 
 if __name__ == "__main__":

@@ -21,12 +21,14 @@ def quantizer(g):
 def replay(g, QuantK, QuantV, device="cpu", v_topk_on_host=True):
     bits, sparse, sinks = int(g["bits"]), bool(g["include_sparse"]), int(g["sinks"])
     S, steps, max_len, theta = int(g["S"]), int(g["steps"]), int(g["max_len"]), float(g["theta"])
+    orig = bool(g["orig"]) if "orig" in g else False
     dev = torch.device(device)
     k_all = torch.from_numpy(g["k_all"]).to(dev)
     v_all = torch.from_numpy(g["v_all"]).to(dev)
     q_all = torch.from_numpy(g["q_all"]).to(dev)
     kc = QuantK(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
-                include_sparse=sparse, sparsity_threshold=0.99, rope_theta=theta, first_few_fp16=sinks)
+                include_sparse=sparse, sparsity_threshold=0.99, rope_theta=theta, first_few_fp16=sinks,
+                **({"use_orig_sparse": True} if orig else {}))
     vc = QuantV(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
                 include_sparse=sparse, sparsity_threshold=0.99, first_few_fp16=sinks)
     kc.load_lookup_table(quantizer(g), include_sparse=sparse, sparsity_threshold=0.99)
@@ -37,7 +39,10 @@ def replay(g, QuantK, QuantV, device="cpu", v_topk_on_host=True):
     if sparse and S > 0:
         ks = k_all[sinks:sinks + S].view(S, H, HD).permute(1, 2, 0)
         vs = v_all[sinks:sinks + S].view(S, H, HD).permute(1, 2, 0)
-        kc.parallel_pack(ks)
+        if orig:
+            kc.parallel_pack_orig(ks)
+        else:
+            kc.parallel_pack(ks)
         kc.klen += sinks
         if v_topk_on_host:
             vflat = v_all[sinks:sinks + S].float()
@@ -55,7 +60,7 @@ def replay(g, QuantK, QuantV, device="cpu", v_topk_on_host=True):
         t = sinks + S + i
         q = q_all[t].view(H, 1, HD)
         k = k_all[t].view(1, H, 1, HD)
-        scores = kc.forward_fused_sparse(q, k)
+        scores = kc.forward_fused_sparse_orig(q, k) if orig else kc.forward_fused_sparse(q, k)
         out["score_%d" % i] = scores
         # feed the golden probabilities so V is checked independently of K rounding
         aw = torch.from_numpy(g["prob_%d" % i]).to(dev)
@@ -72,7 +77,10 @@ def replay(g, QuantK, QuantV, device="cpu", v_topk_on_host=True):
     out["kcache"] = kc.kcache[:, :, :L]
     out["vcache"] = vc.vcache[:, :, :L]
     out["v_lookup_table"] = vc.lookup_table[:L]
-    if sparse:
+    if orig:
+        out["k_rows"], out["k_cols"], out["k_vals"] = kc.rows, kc.cols, kc.vals
+        out["k_start_rows"] = kc.start_rows
+    elif sparse:
         out["k_outliers"] = kc.outliers[:L]
         out["k_outlier_indices"] = kc.outlier_indices[:L]
         out["v_outliers"] = vc.outliers[:L]
@@ -80,7 +88,7 @@ def replay(g, QuantK, QuantV, device="cpu", v_topk_on_host=True):
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
-EXACT_KEYS = ["k_lookup_table", "k_thr_upper", "k_thr_lower", "v_lut", "kcache", "vcache", "v_lookup_table",
+EXACT_KEYS = ["k_rows", "k_cols", "k_vals", "k_start_rows", "k_lookup_table", "k_thr_upper", "k_thr_lower", "v_lut", "kcache", "vcache", "v_lookup_table",
               "k_outliers", "k_outlier_indices", "v_outliers", "v_outlier_indices"]
 
 
