@@ -92,18 +92,12 @@ class Layer:
 
 
 def decode_step(layers, qs, ks, vs, step):
-    """one token through every layer's KV path (GPU-resident: 6 launches per layer, no host sync);
-    returns the last attention output"""
-    from kvquant_amd import ops
-    inv = 1.0 / math.sqrt(HD)
+    """one token through every layer's KV path (GPU-resident: 5 launches per layer, no host sync, fp16
+    activations consumed directly); returns the last attention output"""
+    from kvquant_amd.cache import decode_kv
     out = None
     for li, lay in enumerate(layers):
-        q = qs[li][step].float().transpose(0, 1).contiguous()         # [1,H,hd] f32 (ML:660-663)
-        k = ks[li][step].float()
-        v = vs[li][step].float()
-        scores = lay.k.append_and_score(q, k)                           # f32 [1,H,L]
-        probs, _ = ops.softmax_scale(scores[0], inv)                    # ML:873-874, 1972-1977
-        out = lay.v.append_and_mix(probs.unsqueeze(0), v)               # f32 [1,H,hd]
+        out, _ = decode_kv(lay.k, lay.v, qs[li][step], ks[li][step], vs[li][step])   # f32 [1,H,hd]
     return out.half()
 
 
@@ -116,7 +110,7 @@ class KernelTimers:
 
     def install(self):
         from kvquant_amd import ops
-        self._orig = (ops.score_k, ops.mix_v)
+        self._orig = (ops.score_k_prepared, ops.mix_v)
         pairs = self.pairs
 
         def wrap(fn, key):
@@ -129,12 +123,12 @@ class KernelTimers:
                 pairs[key].append((e0, e1))
                 return r
             return inner
-        ops.score_k = wrap(ops.score_k, "score_k")
+        ops.score_k_prepared = wrap(ops.score_k_prepared, "score_k")
         ops.mix_v = wrap(ops.mix_v, "mix_v")
 
     def uninstall(self):
         from kvquant_amd import ops
-        ops.score_k, ops.mix_v = self._orig
+        ops.score_k_prepared, ops.mix_v = self._orig
 
     def reset(self):
         for k in self.pairs:
@@ -216,7 +210,7 @@ def main():
     qs, ks, vs = [], [], []
     for lay in layers:
         k, v = synth_tokens(total, lay.scale, lay.shift, gen, dev)
-        q = torch.randn(total, H, 1, HD, generator=gen, device=dev).half()
+        q = torch.randn(total, H, HD, generator=gen, device=dev).half()
         qs.append([q[i] for i in range(total)])
         ks.append([k[i] for i in range(total)])
         vs.append([v[i] for i in range(total)])

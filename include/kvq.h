@@ -167,6 +167,29 @@ KVQ_API int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores,
                       int n_sink, float inv_sqrt_hd, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* ---- one-launch decode prologue ------------------------------------------------ */
+
+/* K fused append + V fused append + the query-premultiplied K codebook images for
+ * kvq_score_k_prepared, as three roles of ONE launch (the jobs are independent and
+ * latency-bound).  k, v: [H*hd], q: [H][128] (already RoPE'd), all fp32
+ * (acts_are_half = 0) or all fp16 (1, the model's activation dtype: saves the
+ * reference's three .float() launches).  score_workspace as for kvq_score_k. */
+KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
+                        const float *klut_off, const void *k, const float *lo,
+                        const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
+                        int32_t *vmat, float *vlut_rows, const float *vlut_sorted,
+                        const void *v, float *voutliers, int32_t *vidx, int64_t vcol,
+                        const void *q, int acts_are_half, int thr_k, int H, int hd,
+                        int64_t max_len, void *score_workspace,
+                        size_t score_workspace_bytes, void *stream);
+/* kvq_score_k for q_len = 1 with the tables (and the fp32 query copy) already in
+ * `workspace` (written by kvq_decode_prologue on the same stream). */
+KVQ_API int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const float *lut,
+                         int H, int hd, int64_t L, int64_t max_len, float rope_theta,
+                         int pos_offset, const float *outliers, const int32_t *outlier_idx,
+                         int n_out, int accumulate, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* ---- uncapped ("orig") Dense-and-Sparse variants, 4 bit only ------------------ */
 
 /* VecQuant4AppendVecKSparseOrig + ...2Orig (KCU:691-931): outlier iff x<lo || x>hi ->

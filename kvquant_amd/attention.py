@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .cache import QuantK, QuantV
+from .cache import QuantK, QuantV, decode_kv
 
 
 def rotate_half(x):
@@ -134,18 +134,17 @@ class KVQuantAttention(nn.Module):
             return out.transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
 
         # ---- decode over the compressed cache (ML:1948-2006), GPU-resident --------------------------
-        q32 = query_rope[0].float().transpose(0, 1).contiguous()             # [1, H, hd]
-        k32 = key_states.flatten().float()
-        v32 = value_states.flatten().float()
-        scores = self.kcache.append_and_score(q32, k32)                        # f32 [1, H, L]
         sink_scores = None
         if sinks > 0:
             sink_scores = (torch.matmul(query_rope, self.kcache_fp16) / math.sqrt(hd))[0, :, 0, :].contiguous()
-        probs, sink_probs = ops.softmax_scale(scores[0], inv, sink_scores)     # f32 [H, L], f16 [H, sinks]
-        if self.vcache.include_sparse and not self.vcache.norm:
-            out = self.vcache.append_and_mix(probs.unsqueeze(0), v32)          # f32 [1, H, hd]
+        if self.kcache.include_sparse and self.vcache.include_sparse and not self.vcache.norm:
+            out, sink_probs = decode_kv(self.kcache, self.vcache, query_rope[0, :, 0, :].contiguous(),
+                                        key_states.flatten(), value_states.flatten(), sink_scores)
             out = out.transpose(0, 1).half()                                   # [H, 1, hd]
         else:
+            q32 = query_rope[0].float().transpose(0, 1).contiguous()             # [1, H, hd]
+            scores = self.kcache.append_and_score(q32, key_states.flatten().float())
+            probs, sink_probs = ops.softmax_scale(scores[0], inv, sink_scores)
             out = self.vcache.forward_fused_sparse(probs.unsqueeze(1).half(), value_states)
         out = out.unsqueeze(0)
         if sinks > 0:

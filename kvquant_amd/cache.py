@@ -435,3 +435,34 @@ class QuantV(nn.Module):
         vals = torch.gather(vals, 1, order)
         self.outliers[col0:col0 + S] = vals
         self.outlier_indices[col0:col0 + S] = idx.int()
+
+
+def decode_kv(kc, vc, q, k, v, sink_scores=None):
+    """One decode token through a layer's compressed KV path, GPU-resident, 5 launches:
+    prologue (K append | V append | K tables) -> q.K^T -> softmax (2) -> p.V (+ slab reduce).
+    q: [H, hd] RoPE'd query, k, v: [C] pre-RoPE key / value, all fp16 or all fp32 (no conversion
+    launches).  sink_scores: optional f16 [H, n_sink] already scaled scores of the fp16 sink tokens.
+    Returns (out f32 [1, H, hd], sink_probs f16 [H, n_sink] or None).  Sparse (include_sparse) caches only."""
+    if not (kc.include_sparse and vc.include_sparse) or vc.norm:
+        raise ValueError("decode_kv needs include_sparse caches without V Q-Norm")
+    bits = kc.bits
+    kpos = kc.klen - kc.first_few_fp16
+    vpos = vc.vlen - vc.first_few_fp16
+    lut_off = kc.lookup_table2 if kc.norm else kc.lookup_table
+    ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
+                             kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
+                             vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
+                             kc.num_outliers // 2)
+    kc.klen += 1
+    vc.vlen += 1
+    L = kc.klen - kc.first_few_fp16
+    H = kc.num_heads
+    scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
+    table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
+    ops.score_k_prepared(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws, kc.outliers,
+                         kc.outlier_indices)
+    probs, sink_probs = ops.softmax_scale(scores[0], 1.0 / (kc.head_dim ** 0.5), sink_scores)
+    out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
+    ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.lookup_table, L, vc.outliers, vc.outlier_indices,
+              accumulate=False)
+    return out, sink_probs

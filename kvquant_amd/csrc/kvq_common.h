@@ -3,6 +3,7 @@
 // (LUT rows, rescale, nearest-code compare) are plain mul/add/div sequences;
 // everything that may fuse uses fmaf explicitly.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -12,6 +12,7 @@
 // "sort by index" of the reference (modeling_llama.py:742, 1171), so no sort.
 #include "kvq_common.h"
 #include "kvq_host.h"
+#include "kvq_ktab.h"
 
 namespace kvq {
 
@@ -129,14 +130,38 @@ __device__ __forceinline__ void radix_select_both(const uint32_t (&key)[E], cons
   gt[1] = k - sh.krem[1];
 }
 
-// mode 0: K (rescaled selection, per-channel LUT); mode 1: V (raw selection, per-token LUT built here)
+struct AppendArgs {
+  uint32_t *mat;
+  const float *lut;        // K: [C][N]
+  const float *lut_off;    // K: table the residuals refer to (lut, or the Q-Norm table)
+  float *lut_rows;         // V: [max_len][N], row `col` is written
+  const float *lut_sorted; // V: [N]
+  const void *x;           // [C], fp32 or fp16
+  int x_is_half;
+  const float *lo, *hi;    // K thresholds
+  float *outliers;
+  int32_t *outlier_idx;
+  int thr_k;
+  int C;
+  int64_t max_len;
+  int64_t col;
+};
+
+// K: rescaled selection, per-channel LUT; V: raw selection, per-token LUT row built here.
+// Executed by one whole workgroup of kSelThreads lanes.
 template <int BITS, bool IS_V>
-__global__ __launch_bounds__(kSelThreads) void fused_append_kernel(
-    uint32_t *__restrict__ mat, const float *__restrict__ lut /*K: [C][N]*/, const float *__restrict__ lut_off,
-    float *__restrict__ lut_rows /*V: [max_len][N]*/, const float *__restrict__ lut_sorted /*V: [N]*/,
-    const float *__restrict__ x, const float *__restrict__ lo, const float *__restrict__ hi,
-    float *__restrict__ outliers, int32_t *__restrict__ outlier_idx, int thr_k, int C, int64_t max_len,
-    int64_t col) {
+__device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
+  uint32_t *__restrict__ mat = A.mat;
+  const float *__restrict__ lut = A.lut;
+  const float *__restrict__ lut_off = A.lut_off;
+  float *__restrict__ lut_rows = A.lut_rows;
+  const float *__restrict__ lut_sorted = A.lut_sorted;
+  const float *__restrict__ lo = A.lo;
+  const float *__restrict__ hi = A.hi;
+  float *__restrict__ outliers = A.outliers;
+  int32_t *__restrict__ outlier_idx = A.outlier_idx;
+  const int thr_k = A.thr_k, C = A.C;
+  const int64_t max_len = A.max_len, col = A.col;
   constexpr int N = Fmt<BITS>::kN;
   constexpr int E = kMaxPerLane;
   __shared__ SelShared sh;
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(kSelThreads) void fused_append_kernel(
 #pragma unroll
   for (int e = 0; e < E; e++) {
     ok[e] = e < per && (c0 + e) < C;
-    xv[e] = ok[e] ? x[c0 + e] : 0.f;
+    xv[e] = ok[e] ? ld_act(A.x, c0 + e, A.x_is_half) : 0.f;
   }
   if constexpr (!IS_V) {
 #pragma unroll
@@ -279,25 +304,83 @@ __global__ __launch_bounds__(kSelThreads) void fused_append_kernel(
   }
 }
 
-template <bool IS_V>
-static int launch_fused(int bits, int32_t *mat, const float *lut, const float *lut_off, float *lut_rows,
-                        const float *lut_sorted, const float *x, const float *lo, const float *hi,
-                        float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
-                        int64_t col, hipStream_t st) {
-  const int C = H * hd;
-  if (!mat || !x || !outliers || !outlier_idx || thr_k <= 0 || H <= 0 || hd <= 0 || hd % 32 || col < 0 ||
-      col >= max_len || C > kMaxPerLane * kSelThreads || 2 * (thr_k + 1) > C || C >= 65536)
+template <int BITS, bool IS_V>
+__global__ __launch_bounds__(kSelThreads) void fused_append_kernel(AppendArgs A) {
+  fused_append_body<BITS, IS_V>(A);
+}
+
+// Decode prologue of one layer in ONE launch: workgroup 0 = K fused append, 1 = V fused append,
+// 2.. = query-premultiplied K codebook images (one head each) for kvq_score_k_prepared.  The three jobs
+// are independent; run back to back they cost 27 + 16 + 4 us of mostly latency.
+struct PrologueArgs {
+  AppendArgs k, v;
+  const float *klut;       // [H][128][N] (table source; == k.lut)
+  const void *q;           // [H][128] fp32 or fp16
+  int q_is_half;
+  unsigned char *tab;      // score workspace: tables, then q as fp32
+  float *q32;
+  int H;
+};
+
+template <int BITS>
+__global__ __launch_bounds__(kSelThreads) void decode_prologue_kernel(PrologueArgs P) {
+  if (blockIdx.x == 0) fused_append_body<BITS, false>(P.k);
+  else if (blockIdx.x == 1) fused_append_body<BITS, true>(P.v);
+  else lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.H, (int)blockIdx.x - 2, 0);
+}
+
+static int check_append(bool is_v, const AppendArgs &a, int H, int hd) {
+  if (!a.mat || !a.x || !a.outliers || !a.outlier_idx || a.thr_k <= 0 || H <= 0 || hd <= 0 || hd % 32 ||
+      a.col < 0 || a.col >= a.max_len || a.C > kMaxPerLane * kSelThreads || 2 * (a.thr_k + 1) > a.C ||
+      a.C >= 65536)
     return KVQ_EINVAL;
-  if (IS_V ? (!lut_rows || !lut_sorted) : (!lut || !lut_off || !lo || !hi)) return KVQ_EINVAL;
-  auto m = reinterpret_cast<uint32_t *>(mat);
+  if (is_v ? (!a.lut_rows || !a.lut_sorted) : (!a.lut || !a.lut_off || !a.lo || !a.hi)) return KVQ_EINVAL;
+  return KVQ_OK;
+}
+
+template <bool IS_V>
+static int launch_fused(int bits, const AppendArgs &a, int H, int hd, hipStream_t st) {
+  int rc = check_append(IS_V, a, H, hd);
+  if (rc) return rc;
   dim3 grid(1), block(kSelThreads);
   switch (bits) {
-    case 4: fused_append_kernel<4, IS_V><<<grid, block, 0, st>>>(m, lut, lut_off, lut_rows, lut_sorted, x, lo, hi, outliers, outlier_idx, thr_k, C, max_len, col); break;
-    case 3: fused_append_kernel<3, IS_V><<<grid, block, 0, st>>>(m, lut, lut_off, lut_rows, lut_sorted, x, lo, hi, outliers, outlier_idx, thr_k, C, max_len, col); break;
-    case 2: fused_append_kernel<2, IS_V><<<grid, block, 0, st>>>(m, lut, lut_off, lut_rows, lut_sorted, x, lo, hi, outliers, outlier_idx, thr_k, C, max_len, col); break;
+    case 4: fused_append_kernel<4, IS_V><<<grid, block, 0, st>>>(a); break;
+    case 3: fused_append_kernel<3, IS_V><<<grid, block, 0, st>>>(a); break;
+    case 2: fused_append_kernel<2, IS_V><<<grid, block, 0, st>>>(a); break;
     default: return KVQ_EINVAL;
   }
   return check_launch();
+}
+
+static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, const void *x, int x_is_half,
+                         const float *lo, const float *hi, float *outliers, int32_t *idx, int thr_k, int H, int hd,
+                         int64_t max_len, int64_t col) {
+  AppendArgs a;
+  a.mat = reinterpret_cast<uint32_t *>(mat);
+  a.lut = lut;
+  a.lut_off = lut_off;
+  a.lut_rows = nullptr;
+  a.lut_sorted = nullptr;
+  a.x = x;
+  a.x_is_half = x_is_half;
+  a.lo = lo;
+  a.hi = hi;
+  a.outliers = outliers;
+  a.outlier_idx = idx;
+  a.thr_k = thr_k;
+  a.C = H * hd;
+  a.max_len = max_len;
+  a.col = col;
+  return a;
+}
+
+static AppendArgs v_args(int32_t *mat, float *lut_rows, const float *lut_sorted, const void *x, int x_is_half,
+                         float *outliers, int32_t *idx, int thr_k, int H, int hd, int64_t max_len, int64_t col) {
+  AppendArgs a = k_args(mat, nullptr, nullptr, x, x_is_half, nullptr, nullptr, outliers, idx, thr_k, H, hd, max_len,
+                        col);
+  a.lut_rows = lut_rows;
+  a.lut_sorted = lut_sorted;
+  return a;
 }
 
 }  // namespace kvq
@@ -309,15 +392,49 @@ extern "C" {
 int kvq_append_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_off, const float *x,
                        const float *lo, const float *hi, float *outliers, int32_t *outlier_idx, int thr_k,
                        int H, int hd, int64_t max_len, int64_t col, void *stream) {
-  return launch_fused<false>(bits, mat, lut, lut_off, nullptr, nullptr, x, lo, hi, outliers, outlier_idx, thr_k,
-                             H, hd, max_len, col, (hipStream_t)stream);
+  return launch_fused<false>(bits, k_args(mat, lut, lut_off, x, 0, lo, hi, outliers, outlier_idx, thr_k, H, hd,
+                                          max_len, col), H, hd, (hipStream_t)stream);
 }
 
 int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
                        float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
                        int64_t col, void *stream) {
-  return launch_fused<true>(bits, mat, nullptr, nullptr, lut_rows, lut_sorted, x, nullptr, nullptr, outliers,
-                            outlier_idx, thr_k, H, hd, max_len, col, (hipStream_t)stream);
+  return launch_fused<true>(bits, v_args(mat, lut_rows, lut_sorted, x, 0, outliers, outlier_idx, thr_k, H, hd,
+                                         max_len, col), H, hd, (hipStream_t)stream);
+}
+
+int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klut_off, const void *k,
+                        const float *lo, const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
+                        int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
+                        float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
+                        int thr_k, int H, int hd, int64_t max_len, void *score_workspace,
+                        size_t score_workspace_bytes, void *stream) {
+  if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
+  if (score_workspace_bytes < kvq_score_k_workspace_bytes(bits, 1, H) ||
+      reinterpret_cast<uintptr_t>(score_workspace) % 16)
+    return KVQ_EWORKSPACE;
+  PrologueArgs P;
+  P.k = k_args(kmat, klut, klut_off, k, acts_are_half, lo, hi, koutliers, kidx, thr_k, H, hd, max_len, kcol);
+  P.v = v_args(vmat, vlut_rows, vlut_sorted, v, acts_are_half, voutliers, vidx, thr_k, H, hd, max_len, vcol);
+  int rc = check_append(false, P.k, H, hd);
+  if (rc) return rc;
+  rc = check_append(true, P.v, H, hd);
+  if (rc) return rc;
+  P.klut = klut;
+  P.q = q;
+  P.q_is_half = acts_are_half;
+  P.tab = reinterpret_cast<unsigned char *>(score_workspace);
+  const size_t tabb = bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
+  P.q32 = reinterpret_cast<float *>(P.tab + (size_t)H * tabb);
+  P.H = H;
+  dim3 grid(2 + H), block(kSelThreads);
+  hipStream_t st = (hipStream_t)stream;
+  switch (bits) {
+    case 4: decode_prologue_kernel<4><<<grid, block, 0, st>>>(P); break;
+    case 3: decode_prologue_kernel<3><<<grid, block, 0, st>>>(P); break;
+    default: decode_prologue_kernel<2><<<grid, block, 0, st>>>(P); break;
+  }
+  return check_launch();
 }
 
 }  // extern "C"

@@ -33,6 +33,7 @@
 // Algorithmic HBM bytes per cached token: C*bits/8 (+ 8*n_out sparse) + 4*H.
 #include "kvq_common.h"
 #include "kvq_host.h"
+#include "kvq_ktab.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -55,42 +56,6 @@ struct ScoreKArgs {
   uint32_t n_out_magic;    // ceil(2^32 / n_out): e / n_out == umulhi(e, magic) for e < 2^32 / n_out
   int accumulate;
 };
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// LDS image of one head's codebook, pre-multiplied by the query.  Rotation pair i (0..31) of
-// wave-half ("role") r covers channel k_lo = 32r+i and k_hi = 64+32r+i.  Entry order:
-//   TLO[(i*2 + r)*N + code] = (L[k_lo][code]*q[k_lo],  L[k_lo][code]*q[k_lo+64])
-//   THI[(i*2 + r)*N + code] = (L[k_hi][code]*q[k_hi], -L[k_hi][code]*q[k_hi-64])
-template <int BITS>
-struct KTab {
-  static constexpr int N = Fmt<BITS>::kN;
-  static constexpr int HALF_B = 32 * 2 * N * 8;     // bytes of TLO (= THI)
-  static constexpr int BUF_B = 2 * HALF_B;          // one head
-};
-
-// one workgroup per (head, query row): builds the image in global memory (L2-resident: H*16 KB)
-template <int BITS>
-__global__ __launch_bounds__(256) void lutq_prep_kernel(const float *__restrict__ lut, const float *__restrict__ q,
-                                                        unsigned char *__restrict__ tab, int H) {
-  constexpr int N = Fmt<BITS>::kN;
-  const int h = blockIdx.x, b = blockIdx.y;
-  const float *lh = lut + (int64_t)h * kHeadDim * N;
-  const float *qh = q + ((int64_t)b * H + h) * kHeadDim;
-  unsigned char *dst = tab + ((int64_t)b * H + h) * KTab<BITS>::BUF_B;
-  for (int e4 = threadIdx.x; e4 < kHeadDim * N / 4; e4 += 256) {
-    const int e0 = e4 * 4;
-    const int k = e0 / N, v0 = e0 % N;
-    const float4 l4 = *reinterpret_cast<const float4 *>(lh + e0);
-    const float qa = qh[k];
-    const float qb = (k < 64) ? qh[k + 64] : -qh[k - 64];
-    const int kk = k & 63;
-    const int r = kk >> 5, i = kk & 31;
-    float4 *d = reinterpret_cast<float4 *>(dst + (k >> 6) * KTab<BITS>::HALF_B + (((i * 2 + r) * N + v0) << 3));
-    d[0] = make_float4(l4.x * qa, l4.x * qb, l4.y * qa, l4.y * qb);
-    d[1] = make_float4(l4.z * qa, l4.z * qb, l4.w * qa, l4.w * qb);
-  }
-}
 
 // BITS consecutive word-rows starting at uniform row `row0`, each read at the lane's byte offset `voff`:
 // wave-uniform 64-bit row base in SGPRs + one 32-bit VGPR offset (no per-lane 64-bit address math).
@@ -403,12 +368,17 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
 }
 
 template <int BITS>
-static int dispatch_score(ScoreKArgs a, const float *lut, void *ws, int q_len, float theta, bool sparse,
-                          hipStream_t st) {
-  lutq_prep_kernel<BITS><<<dim3(a.H, q_len), 256, 0, st>>>(lut, a.q, reinterpret_cast<unsigned char *>(ws), a.H);
-  int rc = check_launch();
-  if (rc) return rc;
-  a.tab = reinterpret_cast<const unsigned char *>(ws);
+static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int q_is_half, int tables_ready,
+                          void *ws, int q_len, float theta, bool sparse, hipStream_t st) {
+  unsigned char *tab = reinterpret_cast<unsigned char *>(ws);
+  float *q32 = reinterpret_cast<float *>(tab + (size_t)q_len * a.H * KTab<BITS>::BUF_B);
+  if (!tables_ready) {
+    lutq_prep_kernel<BITS><<<dim3(a.H, q_len), 256, 0, st>>>(lut, q_in, q_is_half, tab, q32, a.H);
+    int rc = check_launch();
+    if (rc) return rc;
+  }
+  a.tab = tab;
+  a.q = q32;   // fp32 copy made by the prep (the sparse phase reads q directly)
   // big tiles (8 waves) once there are enough of them, small tiles for short caches
   if (a.L >= 16384) {
     return sparse ? launch_score<BITS, true, 8>(a, q_len, theta, st) : launch_score<BITS, false, 8>(a, q_len, theta, st);
@@ -428,15 +398,15 @@ extern "C" {
 
 size_t kvq_score_k_workspace_bytes(int bits, int q_len, int H) {
   if (bits < 2 || bits > 4 || q_len <= 0 || H <= 0) return 0;
-  return (size_t)q_len * H * tab_bytes(bits);
+  return (size_t)q_len * H * (tab_bytes(bits) + kHeadDim * sizeof(float));
 }
 
-int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul, const float *lut, int q_len, int H,
-                int hd, int64_t L, int64_t max_len, float rope_theta, int pos_offset, const float *outliers,
-                const int32_t *outlier_idx, int n_out, int accumulate, void *workspace, size_t workspace_bytes,
-                void *stream) {
-  if (!q || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 || L > max_len || bits < 2 ||
-      bits > 4)
+static int score_entry(int bits, const void *q, int q_is_half, int tables_ready, const int32_t *mat, float *mul,
+                       const float *lut, int q_len, int H, int hd, int64_t L, int64_t max_len, float rope_theta,
+                       int pos_offset, const float *outliers, const int32_t *outlier_idx, int n_out, int accumulate,
+                       void *workspace, size_t workspace_bytes, void *stream) {
+  if ((!q && !tables_ready) || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 ||
+      L > max_len || bits < 2 || bits > 4)
     return KVQ_EINVAL;
   const bool sparse = outliers != nullptr;
   if (sparse && (!outlier_idx || n_out <= 0 || n_out > 4096)) return KVQ_EINVAL;
@@ -444,8 +414,9 @@ int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul, const 
   if (!workspace || workspace_bytes < kvq_score_k_workspace_bytes(bits, q_len, H) ||
       reinterpret_cast<uintptr_t>(workspace) % 16)
     return KVQ_EWORKSPACE;
+  if ((int64_t)hd / 32 * bits * max_len * 4 >= (1ll << 32)) return KVQ_EINVAL;   // 32-bit lane offsets
   ScoreKArgs a;
-  a.q = q;
+  a.q = nullptr;
   a.mat = reinterpret_cast<const uint32_t *>(mat);
   a.mul = mul;
   a.tab = nullptr;
@@ -461,10 +432,26 @@ int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul, const 
   a.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
   switch (bits) {
-    case 4: return dispatch_score<4>(a, lut, workspace, q_len, rope_theta, sparse, st);
-    case 3: return dispatch_score<3>(a, lut, workspace, q_len, rope_theta, sparse, st);
-    default: return dispatch_score<2>(a, lut, workspace, q_len, rope_theta, sparse, st);
+    case 4: return dispatch_score<4>(a, lut, q, q_is_half, tables_ready, workspace, q_len, rope_theta, sparse, st);
+    case 3: return dispatch_score<3>(a, lut, q, q_is_half, tables_ready, workspace, q_len, rope_theta, sparse, st);
+    default: return dispatch_score<2>(a, lut, q, q_is_half, tables_ready, workspace, q_len, rope_theta, sparse, st);
   }
+}
+
+int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul, const float *lut, int q_len, int H,
+                int hd, int64_t L, int64_t max_len, float rope_theta, int pos_offset, const float *outliers,
+                const int32_t *outlier_idx, int n_out, int accumulate, void *workspace, size_t workspace_bytes,
+                void *stream) {
+  return score_entry(bits, q, 0, 0, mat, mul, lut, q_len, H, hd, L, max_len, rope_theta, pos_offset, outliers,
+                     outlier_idx, n_out, accumulate, workspace, workspace_bytes, stream);
+}
+
+int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const float *lut, int H, int hd, int64_t L,
+                         int64_t max_len, float rope_theta, int pos_offset, const float *outliers,
+                         const int32_t *outlier_idx, int n_out, int accumulate, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset, outliers,
+                     outlier_idx, n_out, accumulate, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

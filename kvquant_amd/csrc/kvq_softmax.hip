@@ -32,35 +32,59 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// pass 1: per (split, head) running max and sum of exp
+// block-wide (max, sum) merge of per-lane online-softmax state
+__device__ __forceinline__ void block_merge(float &m, float &s, float *red) {
+  // wave level
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float mo = __shfl_xor(m, d), so = __shfl_xor(s, d);
+    const float mn = fmaxf(m, mo);
+    s = (mn == -INFINITY) ? 0.f : s * expf(m - mn) + so * expf(mo - mn);
+    m = mn;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w] = m; red[4 + w] = s; }
+  __syncthreads();
+  float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float S = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (red[i] > -INFINITY) S += red[4 + i] * expf(red[i] - M);
+  m = M;
+  s = S;
+}
+
+// pass 1: per (split, head) max and sum of exp in ONE sweep over the slice (online softmax per lane,
+// 16-byte loads): the scores are read once here and once in pass 2
 __global__ __launch_bounds__(256) void softmax_partial_kernel(const float *__restrict__ scores,
                                                               const __half *__restrict__ sink, float *__restrict__ ws,
                                                               int64_t L, int n_sink, float inv, int nsplit) {
   __shared__ float red[8];
   const int h = blockIdx.y, sp = blockIdx.x;
-  const int64_t per = (L + nsplit - 1) / nsplit;
+  const int64_t per = ((L + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
   const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
   const float *row = scores + (int64_t)h * L;
-  float m = -INFINITY;
-  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) m = fmaxf(m, scaled(row[t], inv));
-  if (sp == 0)
-    for (int i = threadIdx.x; i < n_sink; i += 256) m = fmaxf(m, __half2float(sink[h * n_sink + i]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float s = 0.f;
-  if (m > -INFINITY) {
-    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) s += expf(scaled(row[t], inv) - m);
-    if (sp == 0)
-      for (int i = threadIdx.x; i < n_sink; i += 256) s += expf(__half2float(sink[h * n_sink + i]) - m);
+  float m = -INFINITY, s = 0.f;
+  auto push = [&](float x) {
+    if (x > m) { s = s * expf(m - x) + 1.f; m = x; }   // (m = -inf: s = 0*0 + 1)
+    else s += expf(x - m);
+  };
+  // scalar head up to the first 16-byte aligned element (rows start at h*L floats: any alignment),
+  // vector body, scalar tail
+  int64_t ta = t0 + ((4 - (int64_t)(((reinterpret_cast<uintptr_t>(row) >> 2) + (uint64_t)t0) & 3)) & 3);
+  if (ta > t1) ta = t1;
+  if ((int64_t)threadIdx.x < ta - t0) push(scaled(row[t0 + threadIdx.x], inv));
+  int64_t t = ta + threadIdx.x * 4;
+  for (; t + 3 < t1; t += 1024) {
+    const float4 v = *reinterpret_cast<const float4 *>(row + t);
+    push(scaled(v.x, inv)); push(scaled(v.y, inv)); push(scaled(v.z, inv)); push(scaled(v.w, inv));
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
-  __syncthreads();
+  for (int64_t u = t; u < t1 && u < t + 4; u++) push(scaled(row[u], inv));
+  if (sp == 0)
+    for (int i = threadIdx.x; i < n_sink; i += 256) push(__half2float(sink[h * n_sink + i]));
+  block_merge(m, s, red);
   if (threadIdx.x == 0) {
     ws[(h * nsplit + sp) * 2] = m;
-    ws[(h * nsplit + sp) * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    ws[(h * nsplit + sp) * 2 + 1] = s;
   }
 }
 
@@ -78,12 +102,24 @@ __global__ __launch_bounds__(256) void softmax_final_kernel(const float *__restr
     const float mi = ws[(h * nsplit + i) * 2];
     if (mi > -INFINITY) Z += ws[(h * nsplit + i) * 2 + 1] * expf(mi - M);
   }
-  const int64_t per = (L + nsplit - 1) / nsplit;
+  const int64_t per = ((L + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
   const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
   const float *row = scores + (int64_t)h * L;
   float *out = probs + (int64_t)h * L;
-  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256)
-    out[t] = __half2float(__float2half_rn(expf(scaled(row[t], inv) - M) / Z));
+  auto f = [&](float x) { return __half2float(__float2half_rn(expf(scaled(x, inv) - M) / Z)); };
+  if (((reinterpret_cast<uintptr_t>(row) ^ reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    int64_t ta = t0 + ((4 - (int64_t)(((reinterpret_cast<uintptr_t>(row) >> 2) + (uint64_t)t0) & 3)) & 3);
+    if (ta > t1) ta = t1;
+    if ((int64_t)threadIdx.x < ta - t0) out[t0 + threadIdx.x] = f(row[t0 + threadIdx.x]);
+    int64_t t = ta + threadIdx.x * 4;
+    for (; t + 3 < t1; t += 1024) {
+      const float4 v = *reinterpret_cast<const float4 *>(row + t);
+      *reinterpret_cast<float4 *>(out + t) = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
+    }
+    for (int64_t u = t; u < t1 && u < t + 4; u++) out[u] = f(row[u]);
+  } else {
+    for (int64_t u = t0 + threadIdx.x; u < t1; u += 256) out[u] = f(row[u]);
+  }
   if (sp == 0)
     for (int i = threadIdx.x; i < n_sink; i += 256)
       sink_probs[h * n_sink + i] = __float2half_rn(expf(__half2float(sink[h * n_sink + i]) - M) / Z);

@@ -278,3 +278,46 @@ def spmv_v_csc(colptr, rows, vals, p, mul, num_cols, L):
         _lib.check(_L().kvq_spmv_v_csc(_i(colptr, "cols"), _i(rows, "rows") if rows.numel() else None,
                                        _f(vals, "vals") if vals.numel() else None, _f(p, "vec"), _f(mul, "mul"),
                                        int(num_cols), int(L), H, hd, _stream()), "kvq_spmv_v_csc")
+
+
+# ---- one-launch decode prologue + prepared score ----------------------------------------------------
+def _act(t, name):
+    """activation vector: fp32 or fp16, contiguous, on the GPU -> (ptr, is_half)"""
+    if t.dtype == torch.float16:
+        return _chk(t, torch.float16, name), 1
+    return _chk(t, torch.float32, name), 0
+
+
+def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vmat, vlut_rows, vlut_sorted, v,
+                    voutl, vidx, vcol, q, thr_k):
+    """K fused append + V fused append + K codebook images for score_k_prepared in ONE launch.
+    q [H,128] (RoPE'd), k, v [C]: all fp32 or all fp16.  Returns the score workspace tensor."""
+    H, hd, max_len = _cache_dims(kmat, bits)
+    kp, kh = _act(k, "k")
+    vp, vh = _act(v, "v")
+    qp, qh = _act(q, "q")
+    if not (kh == vh == qh):
+        raise ValueError("q, k, v must share one dtype (fp32 or fp16)")
+    with _Dev(kmat):
+        nbytes = _L().kvq_score_k_workspace_bytes(bits, 1, H)
+        ws = _workspace(kmat.device, nbytes, slot="score")
+        _lib.check(_L().kvq_decode_prologue(
+            bits, _i(kmat, "kcache"), _f(klut, "lookup_table"), _f(klut_off, "lut_off"), kp, _f(lo, "lower"),
+            _f(hi, "upper"), _f(koutl, "outliers"), _i(kidx, "outlier_indices"), int(kcol), _i(vmat, "vcache"),
+            _f(vlut_rows, "lookup_table"), _f(vlut_sorted, "lut"), vp, _f(voutl, "outliers"),
+            _i(vidx, "outlier_indices"), int(vcol), qp, kh, int(thr_k), H, hd, max_len, ws.data_ptr(),
+            ws.numel(), _stream()), "kvq_decode_prologue")
+    return ws
+
+
+def score_k_prepared(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers=None, outlier_indices=None,
+                     accumulate=False):
+    """score kernel only (q_len = 1); tables + q were written to `ws` by decode_prologue."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    n_out = 0 if outliers is None else outliers.shape[1]
+    with _Dev(mat):
+        _lib.check(_L().kvq_score_k_prepared(
+            bits, _i(mat, "mat"), _f(mul, "mul"), _f(lut, "lookup_table"), H, hd, int(L), max_len, float(theta),
+            int(pos_offset), None if outliers is None else _f(outliers, "outliers"),
+            None if outliers is None else _i(outlier_indices, "outlier_indices"), n_out, 1 if accumulate else 0,
+            ws.data_ptr(), ws.numel(), _stream()), "kvq_score_k_prepared")

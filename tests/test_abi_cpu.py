@@ -43,7 +43,7 @@ def test_version_and_errors(lib):
                            None) == -1
     assert lib.kvq_mix_v_workspace_bytes(4, 1, 32, 128, 131072) > 0
     assert lib.kvq_mix_v_workspace_bytes(4, 1, 32, 64, 131072) == 0      # head_dim must be 128
-    assert lib.kvq_score_k_workspace_bytes(4, 1, 32) == 32 * 16384
+    assert lib.kvq_score_k_workspace_bytes(4, 1, 32) == 32 * (16384 + 128 * 4)   # tables + fp32 copy of q
 
 
 def test_legacy_module_surface():
