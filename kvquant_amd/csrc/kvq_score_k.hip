@@ -84,8 +84,6 @@ __device__ __forceinline__ uint32_t byte_of(uint32_t x) {
 }
 
 constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse variant (LDS budget: 32 KB score tile)
-constexpr int kSparseChunks = 21;   // 64-entry chunks a wave holds at once: 32*n_out/64 = 21 at n_out = 42;
-                                    // wider rows take further rounds
 
 template <int BITS, bool SPARSE, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
@@ -94,7 +92,8 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   constexpr int T = NWAVES * 32;
   constexpr int NT = NWAVES * 64;
   constexpr int TAB_B = KTab<BITS>::BUF_B;
-  constexpr int SCS = kSparseHpg + 1;   // score-tile row stride (token-major, padded: see the sparse phase)
+  constexpr int SCS = kSparseHpg;       // score-tile row stride (token-major; the column is rotated by the
+                                        // token so that neither the per-token nor the per-head access conflicts)
   constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
   constexpr int TAB_DMA = TAB_B / 1024;                        // 16-byte-per-lane DMA instructions per table
   constexpr int TAB_DMA_W = (TAB_DMA + NWAVES - 1) / NWAVES;   // ... per wave
@@ -102,13 +101,11 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   // static LDS: every table offset below is a compile-time constant that folds into ds immediates
   // q of the group's heads for the sparse phase: 16 KB.  With 4-bit tables it aliases table buffer 1, which
   // is first written (by the DMA for the second head) after the sparse phase; smaller tables leave room.
-  constexpr bool QL_ALIAS = TAB_B >= kSparseHpg * kHeadDim * 4;
-  constexpr int QL_B = (SPARSE && !QL_ALIAS) ? kSparseHpg * kHeadDim * 4 : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TAB_B + 256 + SC_B + QL_B];
+  constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TAB_B + SC_B + QL_B];
   unsigned char *lutq = smem;                                                    // [2][TAB_B]
-  float *theta = reinterpret_cast<float *>(smem + 2 * TAB_B);                    // [64]
-  float *sc = reinterpret_cast<float *>(smem + 2 * TAB_B + 256);                 // [T][SCS]
-  float *ql = reinterpret_cast<float *>(QL_ALIAS ? smem + TAB_B : smem + 2 * TAB_B + 256 + SC_B);   // [hpg][128]
+  float *sc = reinterpret_cast<float *>(smem + 2 * TAB_B);                       // [T][SCS]
+  float *ql = reinterpret_cast<float *>(smem + 2 * TAB_B + SC_B);                // [hpg][128]
   const uint32_t lds0 = lds_addr(smem);
 
   const int tid = threadIdx.x;
@@ -136,34 +133,34 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   };
 
   // ---- sparse entries of the tile.  Wave w owns the 32 tokens it also decodes densely: a contiguous run
-  // of 32*n_out entries, walked in 64-lane chunks (fully coalesced, all lanes busy).  ALL chunk loads go
-  // out before anything else (kSparseChunks x 2 VGPRs; the 64 trig registers are not live yet), so the HBM
-  // latency is paid once per tile.
+  // of 32*n_out entries, walked in 64-lane chunks (fully coalesced, all lanes busy), ONE CHUNK PER HEAD
+  // ITERATION of the dense loop, fetched one iteration ahead: the sparse work hides in the dense loop's
+  // memory waits instead of being a serial, latency-bound prologue in every workgroup at once.
   const bool do_sparse = SPARSE && b == 0 && a.outliers != nullptr;   // reference: batch 0 only (KCU:3605)
   const int ntok = (a.L - tile0 < T) ? (int)(a.L - tile0) : T;
   const unsigned nent = do_sparse ? (unsigned)ntok * (unsigned)a.n_out : 0u;   // entries of the tile
   const unsigned wbase = (unsigned)wave * 32u * (unsigned)a.n_out;             // this wave's first entry
   const unsigned wcnt = 32u * (unsigned)a.n_out;                               // ... and how many
+  const int nchunks = do_sparse ? (int)((wcnt + 63) / 64) : 0;
   const float *ov = a.outliers + tile0 * a.n_out;
   const int32_t *oi = a.idx + tile0 * a.n_out;
-  constexpr int SPL = SPARSE ? kSparseChunks : 1;
-  float sv[SPL];
-  int si[SPL];
+  // chunk j of this wave -> (val, col) registers, asm loads outside hipcc's scoreboard (clamped index)
+  auto sparse_fetch = [&](int j, float &val, int &col) {
+    const unsigned e = wbase + (unsigned)j * 64 + lane;
+    const unsigned ec = (e < nent ? e : (nent ? nent - 1 : 0)) * 4u;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(val) : "v"(ec), "s"(ov) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(col) : "v"(ec), "s"(oi) : "memory");
+  };
+  float spv = 0.f;
+  int spc = 0;
   if constexpr (SPARSE) {
-    if (nent > 0) {   // wave-uniform; the loads themselves are unconditional (clamped index): a per-element
-                      // "load or zero" makes hipcc branch around every load and drain vmcnt each time
-#pragma unroll
-      for (int j = 0; j < SPL; j++) {
-        const unsigned e = wbase + j * 64 + lane;
-        const unsigned ec = e < nent ? e : nent - 1;
-        sv[j] = ov[ec];
-        si[j] = oi[ec];
-      }
-    }
+    if (nchunks > 0) sparse_fetch(0, spv, spc);
   }
 
   issue_table(0, 0);
-  if (tid < 64) theta[tid] = fr.f[tid];
+  // RoPE frequency j lives in lane j of one VGPR (64 lanes = 64 frequencies); theta_of(j) is a wave shuffle
+  const float th_reg = fr.f[lane];
+  auto theta_of = [&](int j) { return __shfl(th_reg, j); };
   if constexpr (SPARSE) {
     for (int i = tid; i < T * SCS; i += NT) sc[i] = 0.f;
     for (int i = tid; i < a.hpg * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
@@ -176,67 +173,51 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   load_words<BITS>(wA_lo, a.mat, (int64_t)h0 * WPH, a.max_len, woff);
   load_words<BITS>(wA_hi, a.mat, (int64_t)h0 * WPH + 2 * BITS, a.max_len, woff);
 
-  __syncthreads();   // theta / sc / ql visible
+  __syncthreads();   // sc / ql visible
 
-  if constexpr (SPARSE) {
-    // The entries of a token are sorted by channel, so equal (token, head) keys are contiguous in the flat
-    // entry stream.  Per 64-entry chunk: every lane evaluates its entry, a 6-step segmented inclusive scan
-    // (wave shuffles) sums each run, and the run's LAST lane adds the sum into the LDS score tile with a
-    // plain read-modify-write: keys are distinct within a chunk and the wave owns its tokens, so no atomics
-    // (ds_add_f32 costs ~3 cycles per LANE on gfx950 and dominated this phase).
-    const int pos0 = (int)tile0 + a.pos_offset;
-    for (unsigned base = 0; base < wcnt && nent > 0; base += SPL * 64) {
-      if (base > 0) {   // rows wider than 42: further rounds (not on the nuq 1 % path)
+  // One 64-entry chunk of the wave's sparse run.  The entries of a token are sorted by channel, so equal
+  // (token, head) keys are contiguous in the flat entry stream: every lane evaluates its entry, a 6-step
+  // segmented inclusive scan (wave shuffles) sums each run, and the run's LAST lane adds the sum into the
+  // LDS score tile with a plain read-modify-write.  Keys are distinct within a chunk and a wave owns its
+  // tokens' tile rows (the dense epilogue of the same wave adds into them too), so program order is
+  // enough: no atomics (ds_add_f32 costs ~2.6 cycles per LANE on gfx950, measured).
+  const int pos0 = (int)tile0 + a.pos_offset;
+  auto sparse_chunk = [&](int j, float val, int col) {
+    const unsigned el = (unsigned)j * 64 + lane;         // entry within the wave's run
+    const unsigned e = wbase + el;
+    const bool in = (el < wcnt) && (e < nent);
+    const int hh = (col >> 7) - h0;
+    // capped-away slot (zero, modeling_llama.py:745-747) or another head group: contributes nothing
+    const bool use = in && (val != 0.f) && ((unsigned)hh < (unsigned)a.hpg);
+    const unsigned tle = __umulhi(e, a.n_out_magic);     // token within the tile
+    const int ch = col & 127;
+    const float ang = theta_of(ch & 63) * (float)(pos0 + (int)tle);
+    float sn, c;
+    sincos_rev(ang, sn, c);
+    const int hq = use ? hh : 0;
+    const float q1 = ql[hq * kHeadDim + ch];
+    const float q2 = ql[hq * kHeadDim + ((ch + 64) & 127)];
+    const float sg = (ch < 64) ? sn : -sn;
+    float sum = use ? val * fmaf(c, q1, sg * q2) : 0.f;
+    // run key = (token, TRUE head): a zeroed or foreign-group entry keeps its own head, it just carries 0
+    const int key = in ? (int)(tle * 1024 + (unsigned)((col >> 7) & 1023)) : -1 - lane;
 #pragma unroll
-        for (int j = 0; j < SPL; j++) {
-          const unsigned e = wbase + base + j * 64 + lane;
-          const unsigned ec = e < nent ? e : nent - 1;
-          sv[j] = ov[ec];
-          si[j] = oi[ec];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < SPL; j++) {
-        const unsigned el = base + j * 64 + lane;          // entry within the wave's run
-        const unsigned e = wbase + el;
-        const bool in = (el < wcnt) && (e < nent);
-        const float val = sv[j];
-        const int col = si[j];
-        const int hh = (col >> 7) - h0;
-        // capped-away slot (zero, modeling_llama.py:745-747) or another head group: contributes nothing
-        const bool use = in && (val != 0.f) && ((unsigned)hh < (unsigned)a.hpg);
-        const unsigned tle = __umulhi(e, a.n_out_magic);   // token within the tile
-        const int ch = col & 127;
-        const float ang = theta[ch & 63] * (float)(pos0 + (int)tle);
-        float sn, c;
-        sincos_rev(ang, sn, c);
-        const int hq = use ? hh : 0;
-        const float q1 = ql[hq * kHeadDim + ch];
-        const float q2 = ql[hq * kHeadDim + ((ch + 64) & 127)];
-        const float sg = (ch < 64) ? sn : -sn;
-        float sum = use ? val * fmaf(c, q1, sg * q2) : 0.f;
-        // run key = (token, TRUE head): equal keys are contiguous because a token's entries are sorted by
-        // channel (a zeroed or foreign-group entry keeps its own head, it just carries 0)
-        const int key = in ? (int)(tle * 1024 + (unsigned)((col >> 7) & 1023)) : -1 - lane;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const float vu = __shfl_up(sum, d);
-          const int ku = __shfl_up(key, d);
-          if (lane >= d && ku == key) sum += vu;
-        }
-        const int kn = __shfl_down(key, 1);
-        const bool tail = (lane == 63) || (kn != key);
-        if (tail && in && sum != 0.f && (unsigned)hh < (unsigned)a.hpg) sc[tle * SCS + hh] += sum;
-      }
+    for (int d = 1; d < 64; d <<= 1) {
+      const float vu = __shfl_up(sum, d);
+      const int ku = __shfl_up(key, d);
+      if (lane >= d && ku == key) sum += vu;
     }
-  }
+    const int kn = __shfl_down(key, 1);
+    const bool tail = (lane == 63) || (kn != key);
+    if (tail && in && sum != 0.f && (unsigned)hh < (unsigned)a.hpg) sc[tle * SCS + ((hh + tle) & (SCS - 1))] += sum;
+  };
 
   // RoPE angles of this lane's token for its 32 rotation pairs (KCU:3083, 3122-3123)
   f32x2 cs[32];   // (cos, sin)
   const float posf = (float)((int)tc + a.pos_offset);
   static_for<0, 32>([&](auto I) {
     constexpr int i = decltype(I)::value;
-    const float ang = theta[role * 32 + i] * posf;
+    const float ang = theta_of(role * 32 + i) * posf;
     float sn, c;
     sincos_rev(ang, sn, c);
     cs[i].x = c;
@@ -317,11 +298,23 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     float res = acc.x + acc.y;
     res += __shfl_xor(res, 32);
-    if (role == 0 && valid) {
-      if constexpr (SPARSE) res += sc[tl * SCS + hh];
-      float *dst = a.mul + ((int64_t)b * a.H + h) * a.L + t;
-      if (a.accumulate) res += *dst;
-      __builtin_nontemporal_store(res, dst);
+    if constexpr (SPARSE) {
+      // scores of the tile collect in LDS (dense part here, sparse runs whenever their chunk comes up) and
+      // are written out once after the last head
+      if (role == 0) sc[tl * SCS + ((hh + tl) & (SCS - 1))] += res;
+      __builtin_amdgcn_sched_barrier(0);   // keep the sparse chunk's temporaries out of the dense section
+      if (hh < nchunks) {
+        const float v = spv;
+        const int cidx = spc;
+        if (hh + 1 < nchunks && hh + 1 < a.hpg) sparse_fetch(hh + 1, spv, spc);   // waited for by the next head's vm_wait<0>
+        sparse_chunk(hh, v, cidx);
+      }
+    } else {
+      if (role == 0 && valid) {
+        float *dst = a.mul + ((int64_t)b * a.H + h) * a.L + t;
+        if (a.accumulate) res += *dst;
+        __builtin_nontemporal_store(res, dst);
+      }
     }
   };
   for (int hh = 0; hh < a.hpg; hh += 2) {
@@ -329,6 +322,25 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     if (hh + 1 < a.hpg) head(std::integral_constant<int, 1>{}, hh + 1, wB_lo, wB_hi, wA_lo, wA_hi);
   }
   vm_wait<0>();   // the look-ahead loads of the last head
+  if constexpr (SPARSE) {
+    // chunks beyond the number of heads of this workgroup (small head groups / wide rows): serial tail
+    for (int j = a.hpg; j < nchunks; j++) {
+      float v;
+      int cidx;
+      sparse_fetch(j, v, cidx);
+      vm_wait<0>();
+      sparse_chunk(j, v, cidx);
+    }
+    // write the tile out: the two wave halves take alternate heads, 128 B per half-wave per head
+    if (valid) {
+      for (int hh = role; hh < a.hpg; hh += 2) {
+        float res = sc[tl * SCS + ((hh + tl) & (SCS - 1))];
+        float *dst = a.mul + ((int64_t)b * a.H + h0 + hh) * a.L + t;
+        if (a.accumulate) res += *dst;
+        __builtin_nontemporal_store(res, dst);
+      }
+    }
+  }
 }
 
 // theta_j = powf(rope_theta, -2j/128) (KCU:3083): correctly rounded from double
