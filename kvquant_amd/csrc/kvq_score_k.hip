@@ -35,6 +35,9 @@
 #include "kvq_host.h"
 #include "kvq_ktab.h"
 
+#ifndef KVQ_ABL
+#define KVQ_ABL 0
+#endif
 #include <cmath>
 #include <cstdlib>
 
@@ -48,13 +51,17 @@ struct ScoreKArgs {
   const float *outliers;   // [max_len][n_out] or null
   const int32_t *idx;
   int H;
-  int hpg;                 // heads per workgroup
+  int hpg;                 // heads per workgroup (full tiles)
+  int groups;              // head groups per full tile
+  int full_blocks;         // full tiles * groups
+  int hpg_tail;            // heads per workgroup of the ragged last tile
   int64_t L;
   int64_t max_len;
   int pos_offset;
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out): e / n_out == umulhi(e, magic) for e < 2^32 / n_out
   int accumulate;
+  int dbg_tmask;
 };
 
 // BITS consecutive word-rows starting at uniform row `row0`, each read at the lane's byte offset `voff`:
@@ -97,15 +104,22 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
   constexpr int TAB_DMA = TAB_B / 1024;                        // 16-byte-per-lane DMA instructions per table
   constexpr int TAB_DMA_W = (TAB_DMA + NWAVES - 1) / NWAVES;   // ... per wave
+  // look-ahead depth in heads: words and table of head hh+PF-1 are requested at the top of head hh.  The
+  // kernel is bound by bytes in flight (Little's law at ~2 us loaded HBM latency), not by issue: the dense
+  // variant has the registers and the LDS for two heads of look-ahead, the sparse one for one.
+  constexpr int PF = SPARSE ? 2 : 3;
+  // VMEM operations of one look-ahead step that EVERY wave issues (waves with an extra table piece wait
+  // for one more than they need to)
+  constexpr int STEP_OPS = 2 * BITS + TAB_DMA / NWAVES;
 
   // static LDS: every table offset below is a compile-time constant that folds into ds immediates
   // q of the group's heads for the sparse phase: 16 KB.  With 4-bit tables it aliases table buffer 1, which
   // is first written (by the DMA for the second head) after the sparse phase; smaller tables leave room.
   constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TAB_B + SC_B + QL_B];
-  unsigned char *lutq = smem;                                                    // [2][TAB_B]
-  float *sc = reinterpret_cast<float *>(smem + 2 * TAB_B);                       // [T][SCS]
-  float *ql = reinterpret_cast<float *>(smem + 2 * TAB_B + SC_B);                // [hpg][128]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PF * TAB_B + SC_B + QL_B];
+  unsigned char *lutq = smem;                                                    // [PF][TAB_B]
+  float *sc = reinterpret_cast<float *>(smem + PF * TAB_B);                      // [T][SCS]
+  float *ql = reinterpret_cast<float *>(smem + PF * TAB_B + SC_B);               // [hpg][128]
   const uint32_t lds0 = lds_addr(smem);
 
   const int tid = threadIdx.x;
@@ -113,11 +127,25 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = lane >> 5;
   const int tl = wave * 32 + (lane & 31);
-  const int64_t tile0 = (int64_t)blockIdx.x * T;
+  // blocks [0, full_blocks): (full tile, head group) pairs; the ragged last tile -- L % T tokens, present on
+  // almost every decode step -- is cut into single-head-group blocks of hpg_tail heads so that it cannot
+  // become a whole extra round of a grid that otherwise fills the chip exactly once
+  int tile_i, h0_i, nh_i;
+  if ((int)blockIdx.x < a.full_blocks) {
+    tile_i = blockIdx.x / a.groups;
+    h0_i = (blockIdx.x % a.groups) * a.hpg;
+    nh_i = a.hpg;
+  } else {
+    tile_i = a.full_blocks / a.groups;
+    h0_i = ((int)blockIdx.x - a.full_blocks) * a.hpg_tail;
+    nh_i = (a.H - h0_i < a.hpg_tail) ? (a.H - h0_i) : a.hpg_tail;
+  }
+  const int nh = __builtin_amdgcn_readfirstlane(nh_i);   // heads of this workgroup
+  const int64_t tile0 = (int64_t)tile_i * T;
   const int64_t t = tile0 + tl;
   const bool valid = t < a.L;
   const int64_t tc = valid ? t : a.L - 1;
-  const int h0 = blockIdx.y * a.hpg;
+  const int h0 = __builtin_amdgcn_readfirstlane(h0_i);
   const int b = blockIdx.z;
   const float *qb = a.q + (int64_t)b * a.H * kHeadDim;
   const unsigned char *tabb = a.tab + ((int64_t)b * a.H + h0) * TAB_B;
@@ -141,7 +169,9 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   const unsigned nent = do_sparse ? (unsigned)ntok * (unsigned)a.n_out : 0u;   // entries of the tile
   const unsigned wbase = (unsigned)wave * 32u * (unsigned)a.n_out;             // this wave's first entry
   const unsigned wcnt = 32u * (unsigned)a.n_out;                               // ... and how many
-  const int nchunks = do_sparse ? (int)((wcnt + 63) / 64) : 0;
+  const unsigned wavail = nent > wbase ? nent - wbase : 0u;                      // ... that exist (ragged tile)
+  const int nchunks = do_sparse ? (int)(((wavail < wcnt ? wavail : wcnt) + 63) / 64) : 0;
+  const bool wact = wave * 32 < ntok;   // this wave has at least one real token (ragged last tile)
   const float *ov = a.outliers + tile0 * a.n_out;
   const int32_t *oi = a.idx + tile0 * a.n_out;
   // chunk j of this wave -> (val, col) registers, asm loads outside hipcc's scoreboard (clamped index)
@@ -157,21 +187,39 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     if (nchunks > 0) sparse_fetch(0, spv, spc);
   }
 
-  issue_table(0, 0);
   // RoPE frequency j lives in lane j of one VGPR (64 lanes = 64 frequencies); theta_of(j) is a wave shuffle
   const float th_reg = fr.f[lane];
   auto theta_of = [&](int j) { return __shfl(th_reg, j); };
   if constexpr (SPARSE) {
     for (int i = tid; i < T * SCS; i += NT) sc[i] = 0.f;
-    for (int i = tid; i < a.hpg * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
+    for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
   }
 
-  // packed words of the first head (role r: channel groups r and 2+r); the loop loads one head ahead
-  uint32_t wA_lo[BITS], wA_hi[BITS], wB_lo[BITS], wB_hi[BITS];   // even / odd head of the loop
+  // packed words (role r: channel groups r and 2+r) of PF heads rotate through PF register sets
+  uint32_t wlo_all[PF][BITS], whi_all[PF][BITS];
+  float oldv[PF];   // dense + accumulate: the score's previous value travels with the head's words
   // lane offset inside a head's rows: role r starts BITS rows further down (host checks it fits 32 bits)
-  const uint32_t woff = (uint32_t)(((int64_t)role * BITS * a.max_len + tc) * 4);
-  load_words<BITS>(wA_lo, a.mat, (int64_t)h0 * WPH, a.max_len, woff);
-  load_words<BITS>(wA_hi, a.mat, (int64_t)h0 * WPH + 2 * BITS, a.max_len, woff);
+  const uint32_t woff = (uint32_t)(((int64_t)role * BITS * a.max_len + (tc & a.dbg_tmask)) * 4);
+  const bool acc_dense = !SPARSE && a.accumulate;
+  const uint32_t toff = (uint32_t)tc * 4u;
+  auto load_old = [&](float &dst, int hh) {
+    const float *base = a.mul + ((int64_t)b * a.H + h0 + hh) * a.L;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(toff), "s"(base) : "memory");
+  };
+  auto fetch_head = [&](int hh, auto SET) {   // everything head hh needs from memory -> set SET / table SET
+    constexpr int set = decltype(SET)::value;
+#if KVQ_ABL & 4
+    if (hh < 2) issue_table(hh, set);
+#else
+    issue_table(hh, set);
+#endif
+    load_words<BITS>(wlo_all[set], a.mat, (int64_t)(h0 + hh) * WPH, a.max_len, woff);
+    load_words<BITS>(whi_all[set], a.mat, (int64_t)(h0 + hh) * WPH + 2 * BITS, a.max_len, woff);
+    if (acc_dense) load_old(oldv[set], hh);
+  };
+  static_for<0, PF - 1>([&](auto U) {
+    if (decltype(U)::value < nh) fetch_head(decltype(U)::value, U);
+  });
 
   __syncthreads();   // sc / ql visible
 
@@ -188,7 +236,7 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     const bool in = (el < wcnt) && (e < nent);
     const int hh = (col >> 7) - h0;
     // capped-away slot (zero, modeling_llama.py:745-747) or another head group: contributes nothing
-    const bool use = in && (val != 0.f) && ((unsigned)hh < (unsigned)a.hpg);
+    const bool use = in && (val != 0.f) && ((unsigned)hh < (unsigned)nh);
     const unsigned tle = __umulhi(e, a.n_out_magic);     // token within the tile
     const int ch = col & 127;
     const float ang = theta_of(ch & 63) * (float)(pos0 + (int)tle);
@@ -209,7 +257,7 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     }
     const int kn = __shfl_down(key, 1);
     const bool tail = (lane == 63) || (kn != key);
-    if (tail && in && sum != 0.f && (unsigned)hh < (unsigned)a.hpg) sc[tle * SCS + ((hh + tle) & (SCS - 1))] += sum;
+    if (tail && in && sum != 0.f && (unsigned)hh < (unsigned)nh) sc[tle * SCS + ((hh + tle) & (SCS - 1))] += sum;
   };
 
   // RoPE angles of this lane's token for its 32 rotation pairs (KCU:3083, 3122-3123)
@@ -228,25 +276,30 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   const uint32_t rolepat = role ? 0x80808080u : 0u;     // 4 bit: role*128 in every byte
   const uint32_t rolebytes = (uint32_t)role * N * 8;    // generic
 
-  auto head = [&](auto BUF, int hh, uint32_t (&wlo)[BITS], uint32_t (&whi)[BITS], uint32_t (&nlo)[BITS],
-                  uint32_t (&nhi)[BITS]) {
-    constexpr int buf = decltype(BUF)::value;
+  auto head = [&](auto BUF, int hh) {
+    constexpr int buf = decltype(BUF)::value;          // register set and table buffer of this head
+    constexpr int nxt = (buf + PF - 1) % PF;           // ... of head hh+PF-1, free since head hh-1
     const int h = h0 + hh;
-    // table `buf` and this head's words were issued one head ago
-    vm_wait<0>();
-    __syncthreads();  // ... landed for all waves (and sc complete); the other table is free
-    if (hh + 1 < a.hpg) issue_table(hh + 1, 1 - buf);
-    {
-      const int h1 = (hh + 1 < a.hpg) ? h + 1 : h;   // (re-reads a resident line past the last head)
-      load_words<BITS>(nlo, a.mat, (int64_t)h1 * WPH, a.max_len, woff);
-      load_words<BITS>(nhi, a.mat, (int64_t)h1 * WPH + 2 * BITS, a.max_len, woff);
+    uint32_t (&wlo)[BITS] = wlo_all[buf];
+    uint32_t (&whi)[BITS] = whi_all[buf];
+    // this head's table and words were requested PF-1 heads ago; younger requests may stay in flight
+    if (PF > 2 && hh + 1 < nh) {
+      if (acc_dense) vm_wait<(PF - 2) * (STEP_OPS + 1)>();
+      else vm_wait<(PF - 2) * STEP_OPS>();
+    } else {
+      vm_wait<0>();
     }
+#if !(KVQ_ABL & 2)
+    __syncthreads();  // ... landed for all waves (and sc complete); table buffer `nxt` is free
+#endif
+    if (hh + PF - 1 < nh) fetch_head(hh + PF - 1, std::integral_constant<int, nxt>{});
     const unsigned char *tlo = lutq + buf * TAB_B;
     const unsigned char *thi = lutq + buf * TAB_B + KTab<BITS>::HALF_B;
     // 16 look-ups (8 pairs) are issued back to back before their 16 packed FMAs, into 4 independent
     // accumulators: the LDS pipe needs >= 16 reads in flight per wave to run at rate, and a single
     // accumulator would serialise the FMAs
     f32x2 acc4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    if (wact) {
     if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -261,8 +314,13 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
             constexpr int i = 8 * j + n;
             const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
             const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
+#if KVQ_ABL & 1
+            vl[n & 3] = f32x2{__uint_as_float(fl), 1.f};
+            vh[n & 3] = f32x2{__uint_as_float(fh), 1.f};
+#else
             vl[n & 3] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
             vh[n & 3] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+#endif
           });
           static_for<0, 4>([&](auto NN) {
             constexpr int n = 4 * hf + decltype(NN)::value;
@@ -295,36 +353,37 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
         });
       });
     }
+    }   // wact
     const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     float res = acc.x + acc.y;
     res += __shfl_xor(res, 32);
     if constexpr (SPARSE) {
       // scores of the tile collect in LDS (dense part here, sparse runs whenever their chunk comes up) and
       // are written out once after the last head
-      if (role == 0) sc[tl * SCS + ((hh + tl) & (SCS - 1))] += res;
+      if (role == 0 && wact) sc[tl * SCS + ((hh + tl) & (SCS - 1))] += res;
       __builtin_amdgcn_sched_barrier(0);   // keep the sparse chunk's temporaries out of the dense section
       if (hh < nchunks) {
         const float v = spv;
         const int cidx = spc;
-        if (hh + 1 < nchunks && hh + 1 < a.hpg) sparse_fetch(hh + 1, spv, spc);   // waited for by the next head's vm_wait<0>
+        if (hh + 1 < nchunks && hh + 1 < nh) sparse_fetch(hh + 1, spv, spc);   // waited for by the next head's vm_wait<0>
         sparse_chunk(hh, v, cidx);
       }
     } else {
       if (role == 0 && valid) {
         float *dst = a.mul + ((int64_t)b * a.H + h) * a.L + t;
-        if (a.accumulate) res += *dst;
+        if (acc_dense) res += oldv[buf];
         __builtin_nontemporal_store(res, dst);
       }
     }
   };
-  for (int hh = 0; hh < a.hpg; hh += 2) {
-    head(std::integral_constant<int, 0>{}, hh, wA_lo, wA_hi, wB_lo, wB_hi);
-    if (hh + 1 < a.hpg) head(std::integral_constant<int, 1>{}, hh + 1, wB_lo, wB_hi, wA_lo, wA_hi);
+  for (int hb = 0; hb < nh; hb += PF) {
+    static_for<0, PF>([&](auto U) {
+      if (hb + decltype(U)::value < nh) head(U, hb + decltype(U)::value);
+    });
   }
-  vm_wait<0>();   // the look-ahead loads of the last head
   if constexpr (SPARSE) {
     // chunks beyond the number of heads of this workgroup (small head groups / wide rows): serial tail
-    for (int j = a.hpg; j < nchunks; j++) {
+    for (int j = nh; j < nchunks; j++) {
       float v;
       int cidx;
       sparse_fetch(j, v, cidx);
@@ -333,7 +392,7 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     }
     // write the tile out: the two wave halves take alternate heads, 128 B per half-wave per head
     if (valid) {
-      for (int hh = role; hh < a.hpg; hh += 2) {
+      for (int hh = role; hh < nh; hh += 2) {
         float res = sc[tl * SCS + ((hh + tl) & (SCS - 1))];
         float *dst = a.mul + ((int64_t)b * a.H + h0 + hh) * a.L + t;
         if (a.accumulate) res += *dst;
@@ -354,27 +413,52 @@ static RopeFreqs make_freqs(float rope_theta) {
   return fr;
 }
 
-static int pick_groups(int H, int64_t tiles, int max_hpg) {
-  // enough workgroups to fill 256 CUs twice over, heads per group as large as possible (trig
-  // amortisation) but <= max_hpg; groups must divide H.
-  int64_t want = (512 + tiles - 1) / tiles;
-  int g = H;
-  for (int d = 1; d <= H; d++)
-    if (H % d == 0 && H / d <= max_hpg && d >= want) {
-      g = d;
-      break;
+static int workgroup_slots(int wg_per_cu) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return cus * wg_per_cu;
+}
+
+// Head groups per full tile.  A workgroup of hpg heads costs ~(hpg + 2) units (2 = the tile's trig, prologue
+// and epilogue); workgroups run in ceil(n / slots) rounds.  Pick the divisor of H with the cheapest
+// makespan; ties go to the larger group (better trig amortisation).
+static int pick_groups(int H, int64_t tiles, int q_len, int max_hpg, int slots) {
+  int best = H;
+  double best_cost = 1e30;
+  for (int d = 1; d <= H; d++) {
+    if (H % d || H / d > max_hpg) continue;
+    const int64_t n = tiles * d * q_len;
+    const double cost = (double)((n + slots - 1) / slots) * (H / d + 2);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = d;
     }
-  return g;
+  }
+  return best;
 }
 
 template <int BITS, bool SPARSE, int NWAVES>
 static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipStream_t st) {
   constexpr int T = NWAVES * 32;
   ScoreKArgs a = a0;
-  const int64_t tiles = (a.L + T - 1) / T;
-  const int groups = pick_groups(a.H, tiles, SPARSE ? kSparseHpg : 1 << 30);
-  a.hpg = a.H / groups;
-  dim3 grid((unsigned)tiles, groups, q_len), block(NWAVES * 64);
+  const int64_t full_tiles = a.L / T;
+  const int rem = (int)(a.L % T);
+  const int max_hpg = SPARSE ? kSparseHpg : 1 << 30;
+  const int slots = workgroup_slots(16 / NWAVES);      // 128-VGPR kernels: 4 waves per SIMD
+  a.groups = full_tiles ? pick_groups(a.H, full_tiles, q_len, max_hpg, slots) : 1;
+  a.hpg = a.H / a.groups;
+  if (a.hpg > max_hpg) return KVQ_EINVAL;
+  a.full_blocks = (int)(full_tiles * a.groups);
+  // ragged last tile: few heads per workgroup, so that it is a short tail rather than an extra round
+  a.hpg_tail = full_tiles ? (SPARSE ? 4 : 2) : a.H / pick_groups(a.H, 1, q_len, max_hpg, slots);
+  if (a.hpg_tail > a.H) a.hpg_tail = a.H;
+  const int tail_blocks = rem ? (a.H + a.hpg_tail - 1) / a.hpg_tail : 0;
+  dim3 grid((unsigned)(a.full_blocks + tail_blocks), 1, q_len), block(NWAVES * 64);
   score_k_kernel<BITS, SPARSE, NWAVES><<<grid, block, 0, st>>>(a, make_freqs(rope_theta));
   return check_launch();
 }
@@ -442,6 +526,7 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.accumulate = accumulate;
+  a.dbg_tmask = getenv("KVQ_DBG_TMASK") ? atoi(getenv("KVQ_DBG_TMASK")) : -1;
   hipStream_t st = (hipStream_t)stream;
   switch (bits) {
     case 4: return dispatch_score<4>(a, lut, q, q_is_half, tables_ready, workspace, q_len, rope_theta, sparse, st);

@@ -7,6 +7,10 @@ import time
 import torch
 
 sys.path.insert(0, ".")
+import os  # noqa: E402
+if os.environ.get("KVQ_LIB"):      # ablation builds (tools/abl): timing only
+    import kvquant_amd._lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["KVQ_LIB"])
 from kvquant_amd import quant_cuda as qc  # noqa: E402
 
 H, HD, C = 32, 128, 4096
