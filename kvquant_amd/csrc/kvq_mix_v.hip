@@ -351,7 +351,8 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
             acc[i] = fmaf(tab[vcode<BITS, i, WORDS>(w)], pt, acc[i]);
           });
         }
-        __builtin_amdgcn_sched_barrier(0);   // one token's 8..32 look-ups in flight at a time (VGPR budget)
+        if constexpr (e & 1)
+          __builtin_amdgcn_sched_barrier(0);   // two tokens' (8..32 each) look-ups in flight at a time (VGPR budget)
       });
     });
   };
