@@ -110,7 +110,7 @@ class KernelTimers:
 
     def install(self):
         from kvquant_amd import ops
-        self._orig = (ops.score_k_prepared, ops.mix_v)
+        self._orig = (ops.score_k_prepared_softmax, ops.mix_v)
         pairs = self.pairs
 
         def wrap(fn, key):
@@ -123,12 +123,12 @@ class KernelTimers:
                 pairs[key].append((e0, e1))
                 return r
             return inner
-        ops.score_k_prepared = wrap(ops.score_k_prepared, "score_k")
+        ops.score_k_prepared_softmax = wrap(ops.score_k_prepared_softmax, "score_k")   # (+ fused softmax pass 1)
         ops.mix_v = wrap(ops.mix_v, "mix_v")
 
     def uninstall(self):
         from kvquant_amd import ops
-        ops.score_k_prepared, ops.mix_v = self._orig
+        ops.score_k_prepared_softmax, ops.mix_v = self._orig
 
     def reset(self):
         for k in self.pairs:

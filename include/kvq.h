@@ -190,6 +190,25 @@ KVQ_API int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const
                          int n_out, int accumulate, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* First softmax pass fused into the sparse score kernel (it holds each 256-token x H
+ * tile of scores in LDS anyway): kvq_score_k_prepared with accumulate = 0 that also
+ * writes, per head and tile, (max, sum of exp) of the scaled scores
+ * half(half(score) * inv_sqrt_hd) to softmax_parts[H][n_parts][2];
+ * n_parts = kvq_score_k_softmax_parts(bits, L, 1) (0 = shape not supported: use
+ * kvq_softmax_scale).  kvq_softmax_finish is the second pass of kvq_softmax_scale
+ * (modeling_llama.py:1976) on such partials; the fp16 sink scores are merged there. */
+KVQ_API int kvq_score_k_softmax_parts(int bits, int64_t L, int sparse);
+KVQ_API int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul,
+                         const float *lut, int H, int hd, int64_t L, int64_t max_len,
+                         float rope_theta, int pos_offset, const float *outliers,
+                         const int32_t *outlier_idx, int n_out, void *workspace,
+                         size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts,
+                         int n_parts, void *stream);
+KVQ_API int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores,
+                       const float *parts, int n_parts, float *probs,
+                       uint16_t *sink_probs, int H, int64_t L, int n_sink,
+                       float inv_sqrt_hd, void *stream);
+
 /* ---- uncapped ("orig") Dense-and-Sparse variants, 4 bit only ------------------ */
 
 /* VecQuant4AppendVecKSparseOrig + ...2Orig (KCU:691-931): outlier iff x<lo || x>hi ->

@@ -439,7 +439,8 @@ class QuantV(nn.Module):
 
 def decode_kv(kc, vc, q, k, v, sink_scores=None):
     """One decode token through a layer's compressed KV path, GPU-resident, 5 launches:
-    prologue (K append | V append | K tables) -> q.K^T -> softmax (2) -> p.V (+ slab reduce).
+    prologue (K append | V append | K tables) -> q.K^T (+ first softmax pass) -> softmax finish -> p.V -> slab
+    reduce.
     q: [H, hd] RoPE'd query, k, v: [C] pre-RoPE key / value, all fp16 or all fp32 (no conversion
     launches).  sink_scores: optional f16 [H, n_sink] already scaled scores of the fp16 sink tokens.
     Returns (out f32 [1, H, hd], sink_probs f16 [H, n_sink] or None).  Sparse (include_sparse) caches only."""
@@ -459,9 +460,8 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     H = kc.num_heads
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
     table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
-    ops.score_k_prepared(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws, kc.outliers,
-                         kc.outlier_indices)
-    probs, sink_probs = ops.softmax_scale(scores[0], 1.0 / (kc.head_dim ** 0.5), sink_scores)
+    probs, sink_probs = ops.score_k_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
+                                            kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), sink_scores)
     out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.lookup_table, L, vc.outliers, vc.outlier_indices,
               accumulate=False)

@@ -11,6 +11,14 @@
 
 namespace kvq {
 
+// half(half(raw) * inv): the reference casts the scores to fp16 and divides that tensor by a Python scalar
+// on the GPU (modeling_llama.py:873-874, 1972-1973), which torch evaluates as an fp32 multiply by the
+// fp32 reciprocal, rounded back to fp16.
+__device__ __forceinline__ float scaled(float raw, float inv) {
+  const float h = __half2float(__float2half_rn(raw));
+  return __half2float(__float2half_rn(h * inv));
+}
+
 constexpr int kWave = 64;
 constexpr int kHeadDim = 128;  // score / mix kernels (reference BLOCKWIDTH, KCU:43)
 

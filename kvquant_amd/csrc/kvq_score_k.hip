@@ -62,6 +62,11 @@ struct ScoreKArgs {
   uint32_t n_out_magic;    // ceil(2^32 / n_out): e / n_out == umulhi(e, magic) for e < 2^32 / n_out
   int accumulate;
   int dbg_tmask;
+  // optional fusion of the first softmax pass (sparse variant, q_len = 1, accumulate = 0): per (head, tile)
+  // max and sum of exp of the SCALED scores, [H][sm_nparts][2]
+  float *sm_parts;
+  float sm_inv;
+  int sm_nparts;
 };
 
 // BITS consecutive word-rows starting at uniform row `row0`, each read at the lane's byte offset `voff`:
@@ -399,6 +404,38 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
         __builtin_nontemporal_store(res, dst);
       }
     }
+    // First softmax pass on the tile while it is still in LDS (saves a launch and a 4*H*L-byte sweep):
+    // NT/32 lanes per head read the head's column (tokens strided by NT/32), reduce (max, sum of exp) of
+    // the scaled scores among themselves, and lane 0 of each head writes the tile's partial.
+    if (a.sm_parts != nullptr) {
+      __syncthreads();   // a wave wrote only its own tokens' rows
+      constexpr int TPH = NT / 32;
+      const int hh = tid / TPH, r = tid % TPH;
+      float x[T / TPH];
+      float m = -INFINITY, sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < T / TPH; k++) {
+        const int j = r + k * TPH;
+        x[k] = (j < ntok && hh < nh) ? scaled(sc[j * SCS + ((hh + j) & (SCS - 1))], a.sm_inv) : -INFINITY;
+        m = fmaxf(m, x[k]);
+      }
+      if (m > -INFINITY) {
+#pragma unroll
+        for (int k = 0; k < T / TPH; k++) sm += expf(x[k] - m);   // exp(-inf) = 0 for the padding
+      }
+#pragma unroll
+      for (int d = TPH / 2; d >= 1; d >>= 1) {
+        const float mo = __shfl_xor(m, d), so = __shfl_xor(sm, d);
+        const float mn = fmaxf(m, mo);
+        sm = (mn == -INFINITY) ? 0.f : sm * expf(m - mn) + so * expf(mo - mn);
+        m = mn;
+      }
+      if (r == 0 && hh < nh) {
+        float *dst = a.sm_parts + ((int64_t)(h0 + hh) * a.sm_nparts + tile_i) * 2;
+        dst[0] = m;
+        dst[1] = sm;
+      }
+    }
   }
 }
 
@@ -459,6 +496,7 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   if (a.hpg_tail > a.H) a.hpg_tail = a.H;
   const int tail_blocks = rem ? (a.H + a.hpg_tail - 1) / a.hpg_tail : 0;
   dim3 grid((unsigned)(a.full_blocks + tail_blocks), 1, q_len), block(NWAVES * 64);
+  if (a.sm_parts != nullptr && (!SPARSE || a.sm_nparts != (int)((a.L + T - 1) / T))) return KVQ_EINVAL;
   score_k_kernel<BITS, SPARSE, NWAVES><<<grid, block, 0, st>>>(a, make_freqs(rope_theta));
   return check_launch();
 }
@@ -500,7 +538,8 @@ size_t kvq_score_k_workspace_bytes(int bits, int q_len, int H) {
 static int score_entry(int bits, const void *q, int q_is_half, int tables_ready, const int32_t *mat, float *mul,
                        const float *lut, int q_len, int H, int hd, int64_t L, int64_t max_len, float rope_theta,
                        int pos_offset, const float *outliers, const int32_t *outlier_idx, int n_out, int accumulate,
-                       void *workspace, size_t workspace_bytes, void *stream) {
+                       void *workspace, size_t workspace_bytes, void *stream, float *sm_parts = nullptr,
+                       float sm_inv = 0.f, int sm_nparts = 0) {
   if ((!q && !tables_ready) || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 ||
       L > max_len || bits < 2 || bits > 4)
     return KVQ_EINVAL;
@@ -527,6 +566,10 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.accumulate = accumulate;
   a.dbg_tmask = getenv("KVQ_DBG_TMASK") ? atoi(getenv("KVQ_DBG_TMASK")) : -1;
+  a.sm_parts = sm_parts;
+  a.sm_inv = sm_inv;
+  a.sm_nparts = sm_nparts;
+  if (sm_parts && (q_len != 1 || accumulate || !sparse)) return KVQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   switch (bits) {
     case 4: return dispatch_score<4>(a, lut, q, q_is_half, tables_ready, workspace, q_len, rope_theta, sparse, st);
@@ -549,6 +592,23 @@ int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const float *
                          size_t workspace_bytes, void *stream) {
   return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset, outliers,
                      outlier_idx, n_out, accumulate, workspace, workspace_bytes, stream);
+}
+
+/* tiles of the sparse score kernel = (max, sum) partials per head it can write; 0: no fusion for this shape */
+int kvq_score_k_softmax_parts(int bits, int64_t L, int sparse) {
+  if (bits < 2 || bits > 4 || L <= 0 || !sparse) return 0;
+  const int T = L >= 16384 ? 256 : 128;
+  return (int)((L + T - 1) / T);
+}
+
+int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul, const float *lut, int H, int hd,
+                                 int64_t L, int64_t max_len, float rope_theta, int pos_offset,
+                                 const float *outliers, const int32_t *outlier_idx, int n_out, void *workspace,
+                                 size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts, int n_parts,
+                                 void *stream) {
+  if (!softmax_parts || !outliers || n_parts != kvq_score_k_softmax_parts(bits, L, 1)) return KVQ_EINVAL;
+  return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset, outliers,
+                     outlier_idx, n_out, 0, workspace, workspace_bytes, stream, softmax_parts, inv_sqrt_hd, n_parts);
 }
 
 }  // extern "C"

@@ -14,13 +14,6 @@
 
 namespace kvq {
 
-// half(half(raw) * inv): the reference divides an fp16 tensor by a Python scalar
-// on the GPU, which torch evaluates as fp32 multiply by the fp32 reciprocal.
-__device__ __forceinline__ float scaled(float raw, float inv) {
-  const float h = __half2float(__float2half_rn(raw));
-  return __half2float(__float2half_rn(h * inv));
-}
-
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
@@ -93,15 +86,28 @@ __global__ __launch_bounds__(256) void softmax_final_kernel(const float *__restr
                                                             const __half *__restrict__ sink,
                                                             const float *__restrict__ ws, float *__restrict__ probs,
                                                             __half *__restrict__ sink_probs, int64_t L, int n_sink,
-                                                            float inv, int nsplit) {
+                                                            float inv, int nsplit, int n_parts, int sinks_in_parts) {
+  __shared__ float red[8];
   const int h = blockIdx.y, sp = blockIdx.x;
-  float M = -INFINITY;
-  for (int i = 0; i < nsplit; i++) M = fmaxf(M, ws[(h * nsplit + i) * 2]);
-  float Z = 0.f;
-  for (int i = 0; i < nsplit; i++) {
-    const float mi = ws[(h * nsplit + i) * 2];
-    if (mi > -INFINITY) Z += ws[(h * nsplit + i) * 2 + 1] * expf(mi - M);
+  // (max, sum) of the whole row from its n_parts partials (+ the sink scores when the producer of the
+  // partials did not see them): per-lane online merge, then across the block
+  float M = -INFINITY, Z = 0.f;
+  for (int i = threadIdx.x; i < n_parts; i += 256) {
+    const float mi = ws[((int64_t)h * n_parts + i) * 2], si = ws[((int64_t)h * n_parts + i) * 2 + 1];
+    if (mi > -INFINITY) {
+      const float mn = fmaxf(M, mi);
+      Z = Z * expf(M - mn) + si * expf(mi - mn);   // (M = -inf: Z = 0)
+      M = mn;
+    }
   }
+  if (!sinks_in_parts)
+    for (int i = threadIdx.x; i < n_sink; i += 256) {
+      const float x = __half2float(sink[h * n_sink + i]);
+      const float mn = fmaxf(M, x);
+      Z = Z * expf(M - mn) + expf(x - mn);
+      M = mn;
+    }
+  block_merge(M, Z, red);
   const int64_t per = ((L + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
   const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
   const float *row = scores + (int64_t)h * L;
@@ -161,7 +167,20 @@ int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores, float *p
   softmax_final_kernel<<<grid, block, 0, st>>>(scores, reinterpret_cast<const __half *>(sink_scores),
                                                reinterpret_cast<const float *>(workspace), probs,
                                                reinterpret_cast<__half *>(sink_probs), L, n_sink, inv_sqrt_hd,
-                                               nsplit);
+                                               nsplit, nsplit, 1);
+  return check_launch();
+}
+
+int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores, const float *parts, int n_parts,
+                       float *probs, uint16_t *sink_probs, int H, int64_t L, int n_sink, float inv_sqrt_hd,
+                       void *stream) {
+  if (!scores || !probs || !parts || n_parts <= 0 || H <= 0 || L <= 0 || n_sink < 0) return KVQ_EINVAL;
+  if (n_sink > 0 && (!sink_scores || !sink_probs)) return KVQ_EINVAL;
+  const int nsplit = pick_split(H, L);
+  dim3 grid(nsplit, H), block(256);
+  softmax_final_kernel<<<grid, block, 0, (hipStream_t)stream>>>(
+      scores, reinterpret_cast<const __half *>(sink_scores), parts, probs, reinterpret_cast<__half *>(sink_probs), L,
+      n_sink, inv_sqrt_hd, nsplit, n_parts, 0);
   return check_launch();
 }
 

@@ -321,3 +321,47 @@ def score_k_prepared(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers=Non
             int(pos_offset), None if outliers is None else _f(outliers, "outliers"),
             None if outliers is None else _i(outlier_indices, "outlier_indices"), n_out, 1 if accumulate else 0,
             ws.data_ptr(), ws.numel(), _stream()), "kvq_score_k_prepared")
+
+
+def score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices, inv_sqrt_hd,
+                             n_parts):
+    """sparse score kernel (tables already in `ws`, accumulate = 0) that also writes the per-(head, tile)
+    softmax partials; returns the partials buffer (a workspace: consume it before the next call)."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    with _Dev(mat):
+        parts = _workspace(mat.device, H * n_parts * 8, slot="softmax")
+        _lib.check(_L().kvq_score_k_prepared_softmax(
+            bits, _i(mat, "mat"), _f(mul, "mul"), _f(lut, "lookup_table"), H, hd, int(L), max_len, float(theta),
+            int(pos_offset), _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outliers.shape[1],
+            ws.data_ptr(), ws.numel(), float(inv_sqrt_hd), parts.data_ptr(), n_parts, _stream()),
+            "kvq_score_k_prepared_softmax")
+    return parts
+
+
+def softmax_finish(scores, parts, n_parts, inv_sqrt_hd, sink_scores=None):
+    """second softmax pass on partials written by score_k_prepared_softmax; scores f32 [H, L]."""
+    H, L = scores.shape
+    n_sink = 0 if sink_scores is None else sink_scores.shape[1]
+    probs = torch.empty_like(scores)
+    sink_probs = None if n_sink == 0 else torch.empty_like(sink_scores)
+    with _Dev(scores):
+        _lib.check(_L().kvq_softmax_finish(
+            _f(scores, "scores"), None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"),
+            parts.data_ptr(), n_parts, _f(probs, "probs"), None if n_sink == 0 else sink_probs.data_ptr(), H, L,
+            n_sink, float(inv_sqrt_hd), _stream()), "kvq_softmax_finish")
+    return probs, sink_probs
+
+
+def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices, inv_sqrt_hd,
+                    sink_scores=None):
+    """q.K^T (tables already in `ws`) + softmax: `mul` [1, H, L] receives the raw scores; returns
+    (probs f32 [H, L] holding fp16 values, sink_probs f16 [H, n_sink] or None).  Sparse caches take the
+    score kernel with the first softmax pass fused in (2 launches), others score_k_prepared +
+    softmax_scale (3 launches)."""
+    n_parts = _L().kvq_score_k_softmax_parts(bits, int(L), 1 if outliers is not None else 0)
+    if n_parts == 0:
+        score_k_prepared(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices)
+        return softmax_scale(mul[0], inv_sqrt_hd, sink_scores)
+    parts = score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices,
+                                     inv_sqrt_hd, n_parts)
+    return softmax_finish(mul[0], parts, n_parts, inv_sqrt_hd, sink_scores)

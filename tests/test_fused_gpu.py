@@ -113,3 +113,41 @@ def test_softmax_scale(gpu, L, n_sink):
     tol = ref.float().abs() * 2e-3 + 1e-7                    # 1-2 fp16 ulp
     assert bool((d <= tol).all()), float((d - tol).max())
     assert abs(float(got.float().sum(-1).mean()) - 1.0) < 5e-3
+
+
+@pytest.mark.parametrize("bits,L,n_sink", [(4, 300, 0), (4, 20000, 3), (3, 16500, 0), (2, 1000, 2)])
+def test_score_softmax_fused_matches_two_pass(gpu, bits, L, n_sink):
+    """the score kernel with the first softmax pass fused in (+ kvq_softmax_finish) against the plain
+    score kernel + kvq_softmax_scale, and the raw scores against the C oracle"""
+    from kvquant_amd import ops
+    from oracle import ckernels as ck
+    n = 2 ** bits
+    max_len = (L + 64) // 64 * 64
+    g = torch.Generator().manual_seed(bits * 1000 + L)
+    mat = torch.randint(-2 ** 31, 2 ** 31 - 1, (H, HD // 32 * bits, max_len), dtype=torch.int64, generator=g).to(torch.int32)
+    lut = torch.randn(H, HD, n, generator=g).sort(dim=-1).values.contiguous()
+    q = torch.randn(1, H, HD, generator=g)
+    vals = torch.randn(max_len, 42, generator=g)
+    idx = torch.sort(torch.randint(0, C, (max_len, 42), generator=g, dtype=torch.int64), dim=-1).values.to(torch.int32)
+    inv = 1.0 / math.sqrt(HD)
+    sink = (torch.randn(H, n_sink, generator=g) * 3).half().to(gpu) if n_sink else None
+    mg, lg, vg, ig = mat.to(gpu), lut.to(gpu), vals.to(gpu), idx.to(gpu)
+    # two-pass reference on the GPU
+    s2 = torch.zeros(1, H, L, device=gpu)
+    ops.score_k(bits, q.to(gpu), mg, s2, lg, L, 10000.0, 0, vg, ig, accumulate=False)
+    p2, sp2 = ops.softmax_scale(s2[0], inv, sink)
+    # fused: tables through the prologue-free prep inside score_k leave them in the "score" workspace
+    ws = ops._workspace(mg.device, ops._L().kvq_score_k_workspace_bytes(bits, 1, H), slot="score")
+    s1 = torch.zeros(1, H, L, device=gpu)
+    p1, sp1 = ops.score_k_softmax(bits, mg, s1, lg, L, 10000.0, 0, ws, vg, ig, inv, sink)
+    assert torch.equal(s1, s2)
+    d = (p1 - p2).abs()
+    assert bool((d <= p2.abs() * 2e-3 + 1e-7).all()), float(d.max())
+    if n_sink:
+        assert bool(((sp1.float() - sp2.float()).abs() <= sp2.float().abs() * 2e-3 + 1e-7).all())
+    assert abs(float(p1.sum(-1).mean()) + (float(sp1.float().sum(-1).mean()) if n_sink else 0.0) - 1.0) < 5e-3
+    # raw scores against the oracle
+    ref = torch.zeros(1, H, L)
+    ck.score_k(bits, q, mat, ref, lut, L, 10000.0, 0)
+    ck.spmv_k_rope(vals, idx, q, ref, L, 10000.0, 0)
+    assert util.rel_err(s1.cpu().reshape(1, -1), ref.reshape(1, -1)) < 2e-5
