@@ -145,7 +145,7 @@ KVQ_API int kvq_append_k_fused(int bits, int32_t *mat, const float *lut,
                        const float *lut_off, const float *x, const float *lo,
                        const float *hi, float *outliers, int32_t *outlier_idx,
                        int thr_k, int H, int hd, int64_t max_len, int64_t col,
-                       void *stream);
+                       float *outliers_t, int32_t *outlier_idx_t, void *stream);
 
 /* One launch = the V top-(thr_k+1) selection of modeling_llama.py:1537-1545, the
  * per-token codebook row lut_sorted*sf+off written to lut_rows[col] (1086-1114),
@@ -180,8 +180,8 @@ KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
                         int32_t *vmat, float *vlut_rows, const float *vlut_sorted,
                         const void *v, float *voutliers, int32_t *vidx, int64_t vcol,
                         const void *q, int acts_are_half, int thr_k, int H, int hd,
-                        int64_t max_len, void *score_workspace,
-                        size_t score_workspace_bytes, void *stream);
+                        int64_t max_len, float *koutliers_t, int32_t *kidx_t,
+                        void *score_workspace, size_t score_workspace_bytes, void *stream);
 /* kvq_score_k for q_len = 1 with the tables (and the fp32 query copy) already in
  * `workspace` (written by kvq_decode_prologue on the same stream). */
 KVQ_API int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const float *lut,
@@ -196,12 +196,19 @@ KVQ_API int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const
  * half(half(score) * inv_sqrt_hd) to softmax_parts[H][n_parts][2];
  * n_parts = kvq_score_k_softmax_parts(bits, L, 1) (0 = shape not supported: use
  * kvq_softmax_scale).  kvq_softmax_finish is the second pass of kvq_softmax_scale
- * (modeling_llama.py:1976) on such partials; the fp16 sink scores are merged there. */
+ * (modeling_llama.py:1976) on such partials; the fp16 sink scores are merged there.
+ * outliers_t / outlier_idx_t (optional, replace outliers / outlier_idx): the
+ * token-contiguous mirror [n_out][max_len] of the K outlier rows that
+ * kvq_decode_prologue / kvq_append_k_fused maintain when given one -- entries of a
+ * token in the same (ascending channel) order.  With it a lane owns its token's
+ * entries: coalesced loads, no segmented scan (the reference layout costs +23 us at
+ * 128K for exactly that). */
 KVQ_API int kvq_score_k_softmax_parts(int bits, int64_t L, int sparse);
 KVQ_API int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul,
                          const float *lut, int H, int hd, int64_t L, int64_t max_len,
                          float rope_theta, int pos_offset, const float *outliers,
-                         const int32_t *outlier_idx, int n_out, void *workspace,
+                         const int32_t *outlier_idx, int n_out, const float *outliers_t,
+                         const int32_t *outlier_idx_t, void *workspace,
                          size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts,
                          int n_parts, void *stream);
 KVQ_API int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores,

@@ -27,16 +27,16 @@ SIGNATURES = {
     "kvq_score_k": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_mix_v_workspace_bytes": (_sz, [_i, _i, _i, _i, _i64]),
     "kvq_mix_v": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "kvq_append_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "kvq_append_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _vp]),
     "kvq_append_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
     "kvq_softmax_workspace_bytes": (_sz, [_i, _i64]),
     "kvq_softmax_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp, _sz, _vp]),
     "kvq_decode_prologue": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                 _vp, _i, _i, _i, _i, _i64, _vp, _sz, _vp]),
+                                 _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "kvq_score_k_prepared": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_score_k_softmax_parts": (_i, [_i, _i64, _i]),
-    "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _sz, _f, _vp,
-                                          _i, _vp]),
+    "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,
+                                          _sz, _f, _vp, _i, _vp]),
     "kvq_softmax_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp]),
     "kvq_append_k_sparse_orig": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "kvq_append_v_sparse_orig": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),

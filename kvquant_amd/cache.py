@@ -69,6 +69,11 @@ class QuantK(nn.Module):
         if include_sparse:
             self.outliers = torch.zeros((self.max_len, self.num_outliers), dtype=torch.float32, device=dev)
             self.outlier_indices = torch.zeros((self.max_len, self.num_outliers), dtype=torch.int32, device=dev)
+            # token-contiguous mirror of the two buffers above ([slot][token]); kept in step by every append
+            # path of this class and read by the decode score kernel (a lane then owns its token's entries:
+            # coalesced loads, no segmented scan).  +336 B per token next to the reference's layout.
+            self.outliers_t = torch.zeros((self.num_outliers, self.max_len), dtype=torch.float32, device=dev)
+            self.outlier_indices_t = torch.zeros((self.num_outliers, self.max_len), dtype=torch.int32, device=dev)
         self.rope_theta = rope_theta
         self.use_orig_sparse = use_orig_sparse
         self.first_few_fp16 = first_few_fp16
@@ -96,6 +101,8 @@ class QuantK(nn.Module):
         if self.include_sparse:
             self.outliers.zero_()
             self.outlier_indices.zero_()
+            self.outliers_t.zero_()
+            self.outlier_indices_t.zero_()
             self._reset_csr(self.device)
 
     def load_lookup_table(self, quantizer, include_sparse=True, sparsity_threshold=0.99, norm=False):
@@ -158,7 +165,8 @@ class QuantK(nn.Module):
             lut_off = self.lookup_table2 if self.norm else self.lookup_table
             ops.append_k_fused(self.bits, self.kcache, self.lookup_table, lut_off, k,
                                self.outlier_threshold_lower, self.outlier_threshold_upper, self.outliers,
-                               self.outlier_indices, self.num_outliers // 2, pos)
+                               self.outlier_indices, self.num_outliers // 2, pos, self.outliers_t,
+                               self.outlier_indices_t)
         else:
             ops.append_k(self.bits, self.kcache, self.lookup_table, k, pos)
         self.klen += 1
@@ -198,6 +206,8 @@ class QuantK(nn.Module):
         vals, idx = self._outlier_rows(k_t, resc_t)
         self.outliers[col0:col0 + S] = vals
         self.outlier_indices[col0:col0 + S] = idx
+        self.outliers_t[:, col0:col0 + S] = vals.t()
+        self.outlier_indices_t[:, col0:col0 + S] = idx.t()
 
 
     # ---- uncapped outliers (use_orig_sparse=True), 4 bit only ---------------------------------------
@@ -453,7 +463,7 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
                              kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
                              vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
-                             kc.num_outliers // 2)
+                             kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t)
     kc.klen += 1
     vc.vlen += 1
     L = kc.klen - kc.first_few_fp16
@@ -461,7 +471,8 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
     table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
     probs, sink_probs = ops.score_k_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
-                                            kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), sink_scores)
+                                            kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), sink_scores,
+                                            kc.outliers_t, kc.outlier_indices_t)
     out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.lookup_table, L, vc.outliers, vc.outlier_indices,
               accumulate=False)

@@ -141,6 +141,8 @@ struct AppendArgs {
   const float *lo, *hi;    // K thresholds
   float *outliers;
   int32_t *outlier_idx;
+  float *outliers_t;       // K, optional: token-contiguous mirror [2*thr_k][max_len] of the outlier rows
+  int32_t *outlier_idx_t;
   int thr_k;
   int C;
   int64_t max_len;
@@ -194,6 +196,30 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
 #pragma unroll
   for (int e = 0; e < E; e++) key[e] = fkey(sel[e]);
 
+  // K: the codes do not depend on the selection, so the per-channel codebook rows (256 KB, the largest
+  // read of the whole append) are fetched together with x / lo / hi -- one memory round trip instead of two --
+  // and the end points the outlier residuals refer to are kept from the same rows when no Q-Norm table is
+  // in play.
+  float end_lo[E], end_hi[E];
+  const bool same_tab = lut_off == lut;
+  if constexpr (!IS_V) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      end_lo[e] = end_hi[e] = 0.f;
+      if (!ok[e]) continue;
+      float row[N];
+      const float *src = lut + (int64_t)(c0 + e) * N;
+#pragma unroll
+      for (int v = 0; v < N; v += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(src + v);
+        row[v] = t.x; row[v + 1] = t.y; row[v + 2] = t.z; row[v + 3] = t.w;
+      }
+      sh.codes[c0 + e] = nearest_code<N>(row, xv[e]);
+      end_lo[e] = row[0];
+      end_hi[e] = row[N - 1];
+    }
+  }
+
   uint32_t T[2], gt[2];
   const uint32_t ksel = IS_V ? (uint32_t)(thr_k + 1) : (uint32_t)thr_k;   // V: threshold is the (thr_k+1)-th
   radix_select_both<E>(key, ok, ksel, sh, T, gt);
@@ -244,26 +270,16 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
     zp = vrow[Fmt<BITS>::kZeroCode];
   }
 
-  // ---- codes -------------------------------------------------------------------------------------
+  // ---- V codes (need the clip thresholds and the row built above) ----------------------------------------
+  if constexpr (IS_V) {
 #pragma unroll
-  for (int e = 0; e < E; e++) {
-    if (!ok[e]) continue;
-    float row[N];
-    if constexpr (IS_V) {
+    for (int e = 0; e < E; e++) {
+      if (!ok[e]) continue;
+      float row[N];
 #pragma unroll
       for (int v = 0; v < N; v++) row[v] = vrow[v];
-    } else {
-      const float *src = lut + (int64_t)(c0 + e) * N;
-#pragma unroll
-      for (int v = 0; v < N; v += 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(src + v);
-        row[v] = t.x; row[v + 1] = t.y; row[v + 2] = t.z; row[v + 3] = t.w;
-      }
+      sh.codes[c0 + e] = (xv[e] < vmin || xv[e] > vmax) ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, xv[e]);
     }
-    unsigned code;
-    if constexpr (IS_V) code = (xv[e] < vmin || xv[e] > vmax) ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, xv[e]);
-    else code = nearest_code<N>(row, xv[e]);
-    sh.codes[c0 + e] = code;
   }
 
   // ---- outlier row: compaction in channel order ------------------------------------------------------
@@ -282,12 +298,18 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
       const int c = c0 + e;
       // residual to the saturated end point; zero when the rescaled value is inside [-1, 1]
       // (modeling_llama.py:729-747)
-      if (in_hi[e]) val = (sel[e] <= 1.0f) ? 0.f : xv[e] - lut_off[(int64_t)c * N + (N - 1)];
-      else val = (sel[e] >= -1.0f) ? 0.f : xv[e] - lut_off[(int64_t)c * N];
+      if (in_hi[e]) val = (sel[e] <= 1.0f) ? 0.f : xv[e] - (same_tab ? end_hi[e] : lut_off[(int64_t)c * N + (N - 1)]);
+      else val = (sel[e] >= -1.0f) ? 0.f : xv[e] - (same_tab ? end_lo[e] : lut_off[(int64_t)c * N]);
     }
     if ((int)pos < n_out) {
       orow[pos] = val;
       irow[pos] = c0 + e;
+      if constexpr (!IS_V) {
+        if (A.outliers_t != nullptr) {
+          A.outliers_t[(int64_t)pos * max_len + col] = val;
+          A.outlier_idx_t[(int64_t)pos * max_len + col] = c0 + e;
+        }
+      }
     }
     pos++;
   }
@@ -335,6 +357,7 @@ static int check_append(bool is_v, const AppendArgs &a, int H, int hd) {
       a.C >= 65536)
     return KVQ_EINVAL;
   if (is_v ? (!a.lut_rows || !a.lut_sorted) : (!a.lut || !a.lut_off || !a.lo || !a.hi)) return KVQ_EINVAL;
+  if ((a.outliers_t == nullptr) != (a.outlier_idx_t == nullptr)) return KVQ_EINVAL;
   return KVQ_OK;
 }
 
@@ -354,8 +377,10 @@ static int launch_fused(int bits, const AppendArgs &a, int H, int hd, hipStream_
 
 static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, const void *x, int x_is_half,
                          const float *lo, const float *hi, float *outliers, int32_t *idx, int thr_k, int H, int hd,
-                         int64_t max_len, int64_t col) {
+                         int64_t max_len, int64_t col, float *outliers_t = nullptr, int32_t *idx_t = nullptr) {
   AppendArgs a;
+  a.outliers_t = outliers_t;
+  a.outlier_idx_t = idx_t;
   a.mat = reinterpret_cast<uint32_t *>(mat);
   a.lut = lut;
   a.lut_off = lut_off;
@@ -391,9 +416,10 @@ extern "C" {
 
 int kvq_append_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_off, const float *x,
                        const float *lo, const float *hi, float *outliers, int32_t *outlier_idx, int thr_k,
-                       int H, int hd, int64_t max_len, int64_t col, void *stream) {
+                       int H, int hd, int64_t max_len, int64_t col, float *outliers_t, int32_t *outlier_idx_t,
+                       void *stream) {
   return launch_fused<false>(bits, k_args(mat, lut, lut_off, x, 0, lo, hi, outliers, outlier_idx, thr_k, H, hd,
-                                          max_len, col), H, hd, (hipStream_t)stream);
+                                          max_len, col, outliers_t, outlier_idx_t), H, hd, (hipStream_t)stream);
 }
 
 int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
@@ -407,14 +433,15 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
                         const float *lo, const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
                         int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
                         float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
-                        int thr_k, int H, int hd, int64_t max_len, void *score_workspace,
-                        size_t score_workspace_bytes, void *stream) {
+                        int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
+                        void *score_workspace, size_t score_workspace_bytes, void *stream) {
   if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
   if (score_workspace_bytes < kvq_score_k_workspace_bytes(bits, 1, H) ||
       reinterpret_cast<uintptr_t>(score_workspace) % 16)
     return KVQ_EWORKSPACE;
   PrologueArgs P;
-  P.k = k_args(kmat, klut, klut_off, k, acts_are_half, lo, hi, koutliers, kidx, thr_k, H, hd, max_len, kcol);
+  P.k = k_args(kmat, klut, klut_off, k, acts_are_half, lo, hi, koutliers, kidx, thr_k, H, hd, max_len, kcol,
+               koutliers_t, kidx_t);
   P.v = v_args(vmat, vlut_rows, vlut_sorted, v, acts_are_half, voutliers, vidx, thr_k, H, hd, max_len, vcol);
   int rc = check_append(false, P.k, H, hd);
   if (rc) return rc;

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
     dma_wait_all();                       // this wave's DMA pieces of chunk ci have landed
     __syncthreads();                      // ... and everybody else's; the other stage is free again
     if (ci + 1 < n_chunks && !(a.dbg & 2))
-      issue_chunk<BITS>(a, dl, lds0 + (1 - stage) * Cfg::BUF_B, c0 + CT, row_base, n_rows_valid, h0, b);
+      issue_chunk<BITS>(a, dl, lds0 + (1 - stage) * Cfg::BUF_B, (a.dbg & 4) ? t0 : c0 + CT, row_base, n_rows_valid, h0, b);
     const unsigned char *tile = smem + stage * Cfg::BUF_B;
     const unsigned char *lutb = smem + stage * Cfg::BUF_B + Cfg::TILE_B;
     float *pb = reinterpret_cast<float *>(smem + stage * Cfg::BUF_B + Cfg::TILE_B + Cfg::LUT_B);
@@ -388,13 +388,13 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
   }
 }
 
-// mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  32 channels x 8 range lanes per block, 8
-// independent loads in flight per lane.
-__global__ __launch_bounds__(256) void mix_v_reduce_kernel(const float *__restrict__ partial,
-                                                           const float *__restrict__ sparse_partial,
-                                                           float *__restrict__ mul, int n_ranges, int n_sparse,
-                                                           int q_len, int C, int accumulate) {
-  __shared__ float red[8][32];
+// mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  32 channels x 32 range lanes per block (the pass is
+// bound by memory latency: ~700 slabs at 128K, so few slabs per lane and all of a lane's loads in flight).
+__global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restrict__ partial,
+                                                            const float *__restrict__ sparse_partial,
+                                                            float *__restrict__ mul, int n_ranges, int n_sparse,
+                                                            int q_len, int C, int accumulate) {
+  __shared__ float red[32][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int b = blockIdx.y;
@@ -403,14 +403,14 @@ __global__ __launch_bounds__(256) void mix_v_reduce_kernel(const float *__restri
     // dense slabs [r][b][c] and (query row 0 only) sparse slabs [k][c], 8 loads in flight per lane
     auto run = [&](const float *src, int64_t stride, int n) {
       int r = rg;
-      for (; r + 56 < n; r += 64) {
+      for (; r + 7 * 32 < n; r += 8 * 32) {
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(r + 8 * k) * stride];
+        for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(r + 32 * k) * stride];
 #pragma unroll
         for (int k = 0; k < 8; k++) s += v[k];
       }
-      for (; r < n; r += 8) s += src[(int64_t)r * stride];
+      for (; r < n; r += 32) s += src[(int64_t)r * stride];
     };
     run(partial + (int64_t)b * C + c, (int64_t)q_len * C, n_ranges);
     if (b == 0 && n_sparse > 0) run(sparse_partial + c, C, n_sparse);
@@ -418,8 +418,9 @@ __global__ __launch_bounds__(256) void mix_v_reduce_kernel(const float *__restri
   red[rg][cl] = s;
   __syncthreads();
   if (rg == 0 && c < C) {
-    float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) +
-              ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k++) t += red[k][cl];
     if (accumulate) t += mul[(int64_t)b * C + c];
     mul[(int64_t)b * C + c] = t;
   }
@@ -463,7 +464,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st) {
   if (rc) return rc;
   const int C = a.H * kHeadDim;
   dim3 rgrid((C + 31) / 32, a.q_len);
-  mix_v_reduce_kernel<<<rgrid, 256, 0, st>>>(a.partial, a.sparse_partial, mul, pl.n_ranges,
+  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, a.sparse_partial, mul, pl.n_ranges,
                                              a.outliers ? pl.n_ranges * pl.groups : 0, a.q_len, C, accumulate);
   return check_launch();
 }

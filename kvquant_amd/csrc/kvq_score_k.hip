@@ -50,6 +50,8 @@ struct ScoreKArgs {
   const unsigned char *tab;  // [q_len][H][TAB_B] pre-multiplied codebook images (workspace)
   const float *outliers;   // [max_len][n_out] or null
   const int32_t *idx;
+  const float *out_t;      // token-contiguous mirror [n_out][max_len] (TRANSPOSED variant) or null
+  const int32_t *idx_t;
   int H;
   int hpg;                 // heads per workgroup (full tiles)
   int groups;              // head groups per full tile
@@ -97,8 +99,13 @@ __device__ __forceinline__ uint32_t byte_of(uint32_t x) {
 
 constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse variant (LDS budget: 32 KB score tile)
 
-template <int BITS, bool SPARSE, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
+// SPARSE: fused outlier SpMV.  TRANSPOSED (implies SPARSE): the outliers come from the token-contiguous
+// mirror [n_out][max_len] that kvquant_amd's own cache keeps next to the reference's [max_len][n_out]
+// rows: a lane then owns ITS token's entries (coalesced loads, no segmented scan, no index division).
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false>
+__global__ __launch_bounds__(NWAVES * 64, 4) 
+void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
+  static_assert(!TRANSPOSED || SPARSE, "the transposed mirror is a sparse variant");
   constexpr int N = Fmt<BITS>::kN;
   constexpr int WPH = Fmt<BITS>::kWordsPerHead;
   constexpr int T = NWAVES * 32;
@@ -169,28 +176,46 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
   // of 32*n_out entries, walked in 64-lane chunks (fully coalesced, all lanes busy), ONE CHUNK PER HEAD
   // ITERATION of the dense loop, fetched one iteration ahead: the sparse work hides in the dense loop's
   // memory waits instead of being a serial, latency-bound prologue in every workgroup at once.
-  const bool do_sparse = SPARSE && b == 0 && a.outliers != nullptr;   // reference: batch 0 only (KCU:3605)
+  const bool do_sparse = SPARSE && b == 0 && (TRANSPOSED ? a.out_t != nullptr : a.outliers != nullptr);   // reference: batch 0 only (KCU:3605)
   const int ntok = (a.L - tile0 < T) ? (int)(a.L - tile0) : T;
   const unsigned nent = do_sparse ? (unsigned)ntok * (unsigned)a.n_out : 0u;   // entries of the tile
   const unsigned wbase = (unsigned)wave * 32u * (unsigned)a.n_out;             // this wave's first entry
   const unsigned wcnt = 32u * (unsigned)a.n_out;                               // ... and how many
   const unsigned wavail = nent > wbase ? nent - wbase : 0u;                      // ... that exist (ragged tile)
-  const int nchunks = do_sparse ? (int)(((wavail < wcnt ? wavail : wcnt) + 63) / 64) : 0;
+  const int nchunks = (do_sparse && !TRANSPOSED) ? (int)(((wavail < wcnt ? wavail : wcnt) + 63) / 64) : 0;
   const bool wact = wave * 32 < ntok;   // this wave has at least one real token (ragged last tile)
   const float *ov = a.outliers + tile0 * a.n_out;
   const int32_t *oi = a.idx + tile0 * a.n_out;
-  // chunk j of this wave -> (val, col) registers, asm loads outside hipcc's scoreboard (clamped index)
+  // chunk j of this wave -> (val, col) registers (clamped index)
   auto sparse_fetch = [&](int j, float &val, int &col) {
     const unsigned e = wbase + (unsigned)j * 64 + lane;
     const unsigned ec = (e < nent ? e : (nent ? nent - 1 : 0)) * 4u;
     asm volatile("global_load_dword %0, %1, %2" : "=v"(val) : "v"(ec), "s"(ov) : "memory");
     asm volatile("global_load_dword %0, %1, %2" : "=v"(col) : "v"(ec), "s"(oi) : "memory");
   };
-  float spv = 0.f;
-  int spc = 0;
-  if constexpr (SPARSE) {
-    if (nchunks > 0) sparse_fetch(0, spv, spc);
-  }
+  // transposed mirror: role r of token t takes entries [first, first + per) of the token's n_out, one entry
+  // per head iteration, fetched one iteration ahead (64 consecutive tokens per row: 256 contiguous bytes)
+  const int per_t = (a.n_out + 1) >> 1;
+  const int first_t = role ? a.n_out - per_t : 0;       // (odd n_out: role 1's first entry is role 0's last)
+  const int nsteps = (do_sparse && TRANSPOSED && wact) ? per_t : 0;
+  const uint32_t toff_t = (uint32_t)(((int64_t)first_t * a.max_len + tc) * 4);   // host checks the 32-bit range
+  auto sparse_fetch_t = [&](int s2, float &val, int &col) {
+    const float *bv = a.out_t + (int64_t)s2 * a.max_len;
+    const int32_t *bi = a.idx_t + (int64_t)s2 * a.max_len;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(val) : "v"(toff_t), "s"(bv) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(col) : "v"(toff_t), "s"(bi) : "memory");
+  };
+  // The look-ahead (val, col) registers are a two-set ring like the word sets below: a set is written by
+  // asm loads (outside hipcc's vmcnt scoreboard) after the dense section of one unrolled copy of the head
+  // loop and read in the other copy, after that head's explicit vm_wait.  hipcc does not know the loads
+  // are in flight, so nothing may copy or spill a set between its load and that wait: the window is kept
+  // short (the sparse work of the head and the loop back-edge), and every path through a head defines the
+  // other set in place so that the sets are plain loop-carried values without merge copies.  After the wait the
+  // values are ordinary: hipcc may spill them across the dense section as it likes.  tools/check_isa.py
+  // (run by build() and tests/test_isa_cpu.py) verifies the property on the generated code for every asm
+  // load of every variant of this kernel.
+  float spv_all[2] = {0.f, 0.f};
+  int spc_all[2] = {0, 0};
 
   // RoPE frequency j lives in lane j of one VGPR (64 lanes = 64 frequencies); theta_of(j) is a wave shuffle
   const float th_reg = fr.f[lane];
@@ -254,16 +279,39 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     float sum = use ? val * fmaf(c, q1, sg * q2) : 0.f;
     // run key = (token, TRUE head): a zeroed or foreign-group entry keeps its own head, it just carries 0
     const int key = in ? (int)(tle * 1024 + (unsigned)((col >> 7) & 1023)) : -1 - lane;
+#if !(KVQ_ABL & 8)
+    // runs are short (42 entries of a token over 32 heads: ~1.8 on average), so the scan stops as soon as
+    // no lane has a run-mate d lanes below (keys are sorted inside a token: if nobody matches at distance
+    // d, nobody matches further away either)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const float vu = __shfl_up(sum, d);
       const int ku = __shfl_up(key, d);
-      if (lane >= d && ku == key) sum += vu;
+      const bool mate = lane >= d && ku == key;
+      if (!__any(mate)) break;
+      const float vu = __shfl_up(sum, d);
+      if (mate) sum += vu;
     }
+#endif
+#if KVQ_ABL & 8
+    const bool tail = true;
+#else
     const int kn = __shfl_down(key, 1);
     const bool tail = (lane == 63) || (kn != key);
+#endif
+#if KVQ_ABL & 32
+    if (in && sum != 0.f && (unsigned)hh < (unsigned)nh) __hip_atomic_fetch_add(&sc[tle * SCS + ((hh + tle) & (SCS - 1))], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     if (tail && in && sum != 0.f && (unsigned)hh < (unsigned)nh) sc[tle * SCS + ((hh + tle) & (SCS - 1))] += sum;
+#endif
   };
+
+  // first look-ahead set: after the barrier above (its latency hides behind the trig below), checked like
+  // every other asm load by tools/check_isa.py
+  if constexpr (TRANSPOSED) {
+    if (nsteps > 0) sparse_fetch_t(0, spv_all[0], spc_all[0]);
+  } else if constexpr (SPARSE) {
+    if (nchunks > 0) sparse_fetch(0, spv_all[0], spc_all[0]);
+  }
 
   // RoPE angles of this lane's token for its 32 rotation pairs (KCU:3083, 3122-3123)
   f32x2 cs[32];   // (cos, sin)
@@ -276,6 +324,32 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
     cs[i].x = c;
     cs[i].y = sn;
   });
+
+  // One entry of this lane's token (transposed mirror).  The lane owns its token's row of the score tile;
+  // the only other lane that can touch the same (token, head) cell in the same instruction is the other
+  // role half's lane of the same token, so the pair is merged into the role-0 lane first.
+  auto sparse_step_t = [&](int s2, float val, int col) {
+    const bool s_ok = !(role == 1 && (a.n_out & 1) && s2 == 0);
+    const int hhE = (col >> 7) - h0;
+    const int ch = col & 127;
+    bool use = valid && s_ok && (val != 0.f) && ((unsigned)hhE < (unsigned)nh);
+    const float ang = theta_of(ch & 63) * posf;
+    float sn, c;
+    sincos_rev(ang, sn, c);
+    const int hq = use ? hhE : 0;
+    const float q1 = ql[hq * kHeadDim + ch];
+    const float q2 = ql[hq * kHeadDim + (ch ^ 64)];
+    const float sg = (ch < 64) ? sn : -sn;
+    float x = use ? val * fmaf(c, q1, sg * q2) : 0.f;
+    const int hk = use ? hhE : (-1 - role);
+    const int ho = __shfl_xor(hk, 32);
+    const float xo = __shfl_xor(x, 32);
+    if (ho == hk) {
+      if (role == 0) x += xo;
+      else use = false;
+    }
+    if (use) sc[tl * SCS + ((hhE + tl) & (SCS - 1))] += x;
+  };
 
   // per-lane constant part of every look-up address
   const uint32_t rolepat = role ? 0x80808080u : 0u;     // 4 bit: role*128 in every byte
@@ -339,20 +413,23 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
         });
       });
     } else {
-      static_for<0, 4>([&](auto J) {
+      // generic (2 / 3 bit) decode: batches of GB pairs; the sparse variants are at the VGPR limit, and a
+      // spilled look-ahead register is not merely slow but wrong (see the look-ahead sets above)
+      constexpr int GB = SPARSE ? 4 : 8;
+      static_for<0, 32 / GB>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        f32x2 vl[8], vh[8];
-        static_for<0, 8>([&](auto NN) {
+        f32x2 vl[GB], vh[GB];
+        static_for<0, GB>([&](auto NN) {
           constexpr int n = decltype(NN)::value;
-          constexpr int i = 8 * j + n;
+          constexpr int i = GB * j + n;
           const uint32_t fl = (code_of<BITS, i>(wlo) << 3) + rolebytes;
           const uint32_t fh = (code_of<BITS, i>(whi) << 3) + rolebytes;
           vl[n] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
           vh[n] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
         });
-        static_for<0, 8>([&](auto NN) {
+        static_for<0, GB>([&](auto NN) {
           constexpr int n = decltype(NN)::value;
-          constexpr int i = 8 * j + n;
+          constexpr int i = GB * j + n;
           acc4[n & 3] = __builtin_elementwise_fma(cs[i], vl[n], acc4[n & 3]);
           acc4[(n + 2) & 3] = __builtin_elementwise_fma(cs[i], vh[n], acc4[(n + 2) & 3]);
         });
@@ -367,11 +444,19 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
       // are written out once after the last head
       if (role == 0 && wact) sc[tl * SCS + ((hh + tl) & (SCS - 1))] += res;
       __builtin_amdgcn_sched_barrier(0);   // keep the sparse chunk's temporaries out of the dense section
-      if (hh < nchunks) {
-        const float v = spv;
-        const int cidx = spc;
-        if (hh + 1 < nchunks && hh + 1 < nh) sparse_fetch(hh + 1, spv, spc);   // waited for by the next head's vm_wait<0>
-        sparse_chunk(hh, v, cidx);
+      static_assert(!SPARSE || PF == 2, "the sparse look-ahead registers are a two-set ring");
+      // (when there is nothing left to fetch the set is "defined" by an empty asm instead: both paths then
+      // define it in place and hipcc needs no merge copy -- which it would place inside the in-flight window)
+      if constexpr (TRANSPOSED) {
+        if (nsteps > 0) {
+          if (hh + 1 < nsteps) sparse_fetch_t(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);   // waited for by the next head's
+          else asm volatile("" : "=v"(spv_all[1 - (buf & 1)]), "=v"(spc_all[1 - (buf & 1)]));
+          if (hh < nsteps) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);   // landed: this head's vm_wait<0>
+        }
+      } else if (nchunks > 0 && !(KVQ_ABL & 16)) {
+        if (hh + 1 < nchunks) sparse_fetch(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);
+        else asm volatile("" : "=v"(spv_all[1 - (buf & 1)]), "=v"(spc_all[1 - (buf & 1)]));
+        if (hh < nchunks) sparse_chunk(hh, spv_all[buf & 1], spc_all[buf & 1]);
       }
     } else {
       if (role == 0 && valid) {
@@ -393,7 +478,22 @@ __global__ __launch_bounds__(NWAVES * 64, 4) void score_k_kernel(ScoreKArgs a, R
       int cidx;
       sparse_fetch(j, v, cidx);
       vm_wait<0>();
+      asm volatile("" : "+v"(v), "+v"(cidx));   // (the values exist from here on)
       sparse_chunk(j, v, cidx);
+    }
+    if constexpr (TRANSPOSED) {
+      // entries beyond the number of heads of this workgroup (ragged-tile / small-group blocks): two at a
+      // time 
+      for (int s0 = nh; s0 < nsteps; s0 += 2) {
+        float v0, v1 = 0.f;
+        int c0i, c1i = 0;
+        sparse_fetch_t(s0, v0, c0i);
+        if (s0 + 1 < nsteps) sparse_fetch_t(s0 + 1, v1, c1i);
+        vm_wait<0>();
+        asm volatile("" : "+v"(v0), "+v"(c0i), "+v"(v1), "+v"(c1i));   // (the values exist from here on)
+        sparse_step_t(s0, v0, c0i);
+        if (s0 + 1 < nsteps) sparse_step_t(s0 + 1, v1, c1i);
+      }
     }
     // write the tile out: the two wave halves take alternate heads, 128 B per half-wave per head
     if (valid) {
@@ -479,7 +579,7 @@ static int pick_groups(int H, int64_t tiles, int q_len, int max_hpg, int slots) 
   return best;
 }
 
-template <int BITS, bool SPARSE, int NWAVES>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false>
 static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipStream_t st) {
   constexpr int T = NWAVES * 32;
   ScoreKArgs a = a0;
@@ -497,7 +597,7 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   const int tail_blocks = rem ? (a.H + a.hpg_tail - 1) / a.hpg_tail : 0;
   dim3 grid((unsigned)(a.full_blocks + tail_blocks), 1, q_len), block(NWAVES * 64);
   if (a.sm_parts != nullptr && (!SPARSE || a.sm_nparts != (int)((a.L + T - 1) / T))) return KVQ_EINVAL;
-  score_k_kernel<BITS, SPARSE, NWAVES><<<grid, block, 0, st>>>(a, make_freqs(rope_theta));
+  score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED><<<grid, block, 0, st>>>(a, make_freqs(rope_theta));
   return check_launch();
 }
 
@@ -514,6 +614,10 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
   a.tab = tab;
   a.q = q32;   // fp32 copy made by the prep (the sparse phase reads q directly)
   // big tiles (8 waves) once there are enough of them, small tiles for short caches
+  if (a.out_t != nullptr) {
+    return a.L >= 16384 ? launch_score<BITS, true, 8, true>(a, q_len, theta, st)
+                        : launch_score<BITS, true, 4, true>(a, q_len, theta, st);
+  }
   if (a.L >= 16384) {
     return sparse ? launch_score<BITS, true, 8>(a, q_len, theta, st) : launch_score<BITS, false, 8>(a, q_len, theta, st);
   }
@@ -539,12 +643,14 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
                        const float *lut, int q_len, int H, int hd, int64_t L, int64_t max_len, float rope_theta,
                        int pos_offset, const float *outliers, const int32_t *outlier_idx, int n_out, int accumulate,
                        void *workspace, size_t workspace_bytes, void *stream, float *sm_parts = nullptr,
-                       float sm_inv = 0.f, int sm_nparts = 0) {
+                       float sm_inv = 0.f, int sm_nparts = 0, const float *outliers_t = nullptr,
+                       const int32_t *idx_t = nullptr) {
   if ((!q && !tables_ready) || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 ||
       L > max_len || bits < 2 || bits > 4)
     return KVQ_EINVAL;
-  const bool sparse = outliers != nullptr;
-  if (sparse && (!outlier_idx || n_out <= 0 || n_out > 4096)) return KVQ_EINVAL;
+  const bool sparse = outliers != nullptr || outliers_t != nullptr;
+  if (sparse && ((outliers && !outlier_idx) || (outliers_t && !idx_t) || n_out <= 0 || n_out > 4096)) return KVQ_EINVAL;
+  if (outliers_t && (int64_t)n_out * max_len * 4 >= (1ll << 32)) return KVQ_EINVAL;   // 32-bit lane offsets
   if (L == 0) return KVQ_OK;
   if (!workspace || workspace_bytes < kvq_score_k_workspace_bytes(bits, q_len, H) ||
       reinterpret_cast<uintptr_t>(workspace) % 16)
@@ -557,6 +663,8 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
   a.tab = nullptr;
   a.outliers = outliers;
   a.idx = outlier_idx;
+  a.out_t = outliers_t;
+  a.idx_t = idx_t;
   a.H = H;
   a.hpg = H;
   a.L = L;
@@ -603,12 +711,15 @@ int kvq_score_k_softmax_parts(int bits, int64_t L, int sparse) {
 
 int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul, const float *lut, int H, int hd,
                                  int64_t L, int64_t max_len, float rope_theta, int pos_offset,
-                                 const float *outliers, const int32_t *outlier_idx, int n_out, void *workspace,
+                                 const float *outliers, const int32_t *outlier_idx, int n_out,
+                                 const float *outliers_t, const int32_t *outlier_idx_t, void *workspace,
                                  size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts, int n_parts,
                                  void *stream) {
-  if (!softmax_parts || !outliers || n_parts != kvq_score_k_softmax_parts(bits, L, 1)) return KVQ_EINVAL;
-  return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset, outliers,
-                     outlier_idx, n_out, 0, workspace, workspace_bytes, stream, softmax_parts, inv_sqrt_hd, n_parts);
+  if (!softmax_parts || (!outliers && !outliers_t) || n_parts != kvq_score_k_softmax_parts(bits, L, 1))
+    return KVQ_EINVAL;
+  return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset,
+                     outliers_t ? nullptr : outliers, outliers_t ? nullptr : outlier_idx, n_out, 0, workspace,
+                     workspace_bytes, stream, softmax_parts, inv_sqrt_hd, n_parts, outliers_t, outlier_idx_t);
 }
 
 }  // extern "C"

@@ -25,7 +25,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// block-wide (max, sum) merge of per-lane online-softmax state
+// block-wide (max, sum) merge of per-lane online-softmax state (NW waves, red[2 * NW])
+template <int NW = 4>
 __device__ __forceinline__ void block_merge(float &m, float &s, float *red) {
   // wave level
 #pragma unroll
@@ -36,12 +37,14 @@ __device__ __forceinline__ void block_merge(float &m, float &s, float *red) {
     m = mn;
   }
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[w] = m; red[4 + w] = s; }
+  if ((threadIdx.x & 63) == 0) { red[w] = m; red[NW + w] = s; }
   __syncthreads();
-  float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float M = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; i++) M = fmaxf(M, red[i]);
   float S = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; i++) if (red[i] > -INFINITY) S += red[4 + i] * expf(red[i] - M);
+  for (int i = 0; i < NW; i++) if (red[i] > -INFINITY) S += red[NW + i] * expf(red[i] - M);
   m = M;
   s = S;
 }
@@ -82,17 +85,18 @@ __global__ __launch_bounds__(256) void softmax_partial_kernel(const float *__res
 }
 
 // pass 2: combine the partials of the row, normalise, round to fp16
-__global__ __launch_bounds__(256) void softmax_final_kernel(const float *__restrict__ scores,
+template <int NT>
+__global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restrict__ scores,
                                                             const __half *__restrict__ sink,
                                                             const float *__restrict__ ws, float *__restrict__ probs,
                                                             __half *__restrict__ sink_probs, int64_t L, int n_sink,
                                                             float inv, int nsplit, int n_parts, int sinks_in_parts) {
-  __shared__ float red[8];
+  __shared__ float red[2 * (NT / 64)];
   const int h = blockIdx.y, sp = blockIdx.x;
   // (max, sum) of the whole row from its n_parts partials (+ the sink scores when the producer of the
   // partials did not see them): per-lane online merge, then across the block
   float M = -INFINITY, Z = 0.f;
-  for (int i = threadIdx.x; i < n_parts; i += 256) {
+  for (int i = threadIdx.x; i < n_parts; i += NT) {
     const float mi = ws[((int64_t)h * n_parts + i) * 2], si = ws[((int64_t)h * n_parts + i) * 2 + 1];
     if (mi > -INFINITY) {
       const float mn = fmaxf(M, mi);
@@ -101,13 +105,13 @@ __global__ __launch_bounds__(256) void softmax_final_kernel(const float *__restr
     }
   }
   if (!sinks_in_parts)
-    for (int i = threadIdx.x; i < n_sink; i += 256) {
+    for (int i = threadIdx.x; i < n_sink; i += NT) {
       const float x = __half2float(sink[h * n_sink + i]);
       const float mn = fmaxf(M, x);
       Z = Z * expf(M - mn) + expf(x - mn);
       M = mn;
     }
-  block_merge(M, Z, red);
+  block_merge<NT / 64>(M, Z, red);
   const int64_t per = ((L + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
   const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
   const float *row = scores + (int64_t)h * L;
@@ -118,16 +122,24 @@ __global__ __launch_bounds__(256) void softmax_final_kernel(const float *__restr
     if (ta > t1) ta = t1;
     if ((int64_t)threadIdx.x < ta - t0) out[t0 + threadIdx.x] = f(row[t0 + threadIdx.x]);
     int64_t t = ta + threadIdx.x * 4;
-    for (; t + 3 < t1; t += 1024) {
+    for (; t + 3 * NT * 4 + 3 < t1; t += 4 * NT * 4) {   // four independent 16-byte loads in flight per lane
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const float4 *>(row + t + k * NT * 4);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        *reinterpret_cast<float4 *>(out + t + k * NT * 4) = make_float4(f(v[k].x), f(v[k].y), f(v[k].z), f(v[k].w));
+    }
+    for (; t + 3 < t1; t += NT * 4) {
       const float4 v = *reinterpret_cast<const float4 *>(row + t);
       *reinterpret_cast<float4 *>(out + t) = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
     }
     for (int64_t u = t; u < t1 && u < t + 4; u++) out[u] = f(row[u]);
   } else {
-    for (int64_t u = t0 + threadIdx.x; u < t1; u += 256) out[u] = f(row[u]);
+    for (int64_t u = t0 + threadIdx.x; u < t1; u += NT) out[u] = f(row[u]);
   }
   if (sp == 0)
-    for (int i = threadIdx.x; i < n_sink; i += 256)
+    for (int i = threadIdx.x; i < n_sink; i += NT)
       sink_probs[h * n_sink + i] = __float2half_rn(expf(__half2float(sink[h * n_sink + i]) - M) / Z);
 }
 
@@ -164,7 +176,7 @@ int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores, float *p
                                                  reinterpret_cast<float *>(workspace), L, n_sink, inv_sqrt_hd, nsplit);
   int rc = check_launch();
   if (rc) return rc;
-  softmax_final_kernel<<<grid, block, 0, st>>>(scores, reinterpret_cast<const __half *>(sink_scores),
+  softmax_final_kernel<256><<<grid, block, 0, st>>>(scores, reinterpret_cast<const __half *>(sink_scores),
                                                reinterpret_cast<const float *>(workspace), probs,
                                                reinterpret_cast<__half *>(sink_probs), L, n_sink, inv_sqrt_hd,
                                                nsplit, nsplit, 1);
@@ -176,9 +188,11 @@ int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores, const f
                        void *stream) {
   if (!scores || !probs || !parts || n_parts <= 0 || H <= 0 || L <= 0 || n_sink < 0) return KVQ_EINVAL;
   if (n_sink > 0 && (!sink_scores || !sink_probs)) return KVQ_EINVAL;
+  // 1024-lane workgroups: the (max, sum) merge of the row's partials (one per 256-token tile of the score
+  // kernel) is paid once per 1024 lanes and the streaming part runs at 8 waves per SIMD
   const int nsplit = pick_split(H, L);
-  dim3 grid(nsplit, H), block(256);
-  softmax_final_kernel<<<grid, block, 0, (hipStream_t)stream>>>(
+  dim3 grid(nsplit, H), block(1024);
+  softmax_final_kernel<1024><<<grid, block, 0, (hipStream_t)stream>>>(
       scores, reinterpret_cast<const __half *>(sink_scores), parts, probs, reinterpret_cast<__half *>(sink_probs), L,
       n_sink, inv_sqrt_hd, nsplit, n_parts, 0);
   return check_launch();

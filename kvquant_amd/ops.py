@@ -161,7 +161,17 @@ def mix_v(bits, p, mat, mul, lut_rows, L, outliers=None, outlier_indices=None, a
             1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "kvq_mix_v")
 
 
-def append_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, thr_k, col):
+def _mirror(outliers_t, outlier_indices_t, thr_k, max_len):
+    """(ptr, ptr) of the optional token-contiguous K outlier mirror [2*thr_k, max_len], or (None, None)"""
+    if outliers_t is None:
+        return None, None
+    if tuple(outliers_t.shape) != (2 * thr_k, max_len) or tuple(outlier_indices_t.shape) != (2 * thr_k, max_len):
+        raise ValueError("the outlier mirror must be [%d, %d]" % (2 * thr_k, max_len))
+    return _f(outliers_t, "outliers_t"), _i(outlier_indices_t, "outlier_indices_t")
+
+
+def append_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, thr_k, col, outliers_t=None,
+                   outlier_indices_t=None):
     """pack + rescale + exact top-thr_k selection + outlier row, one launch (include/kvq.h)."""
     H, hd, max_len = _cache_dims(mat, bits)
     if outliers.shape[1] != 2 * thr_k or outlier_indices.shape[1] != 2 * thr_k:
@@ -170,7 +180,9 @@ def append_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices
         _lib.check(_L().kvq_append_k_fused(bits, _i(mat, "mat"), _f(lut, "lookup_table"), _f(lut_off, "lut_off"),
                                            _f(x, "newvec"), _f(lo, "lower"), _f(hi, "upper"),
                                            _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"),
-                                           int(thr_k), H, hd, max_len, int(col), _stream()), "kvq_append_k_fused")
+                                           int(thr_k), H, hd, max_len, int(col),
+                                           *_mirror(outliers_t, outlier_indices_t, thr_k, max_len), _stream()),
+                   "kvq_append_k_fused")
 
 
 def append_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col):
@@ -289,7 +301,7 @@ def _act(t, name):
 
 
 def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vmat, vlut_rows, vlut_sorted, v,
-                    voutl, vidx, vcol, q, thr_k):
+                    voutl, vidx, vcol, q, thr_k, koutl_t=None, kidx_t=None):
     """K fused append + V fused append + K codebook images for score_k_prepared in ONE launch.
     q [H,128] (RoPE'd), k, v [C]: all fp32 or all fp16.  Returns the score workspace tensor."""
     H, hd, max_len = _cache_dims(kmat, bits)
@@ -305,8 +317,8 @@ def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vm
             bits, _i(kmat, "kcache"), _f(klut, "lookup_table"), _f(klut_off, "lut_off"), kp, _f(lo, "lower"),
             _f(hi, "upper"), _f(koutl, "outliers"), _i(kidx, "outlier_indices"), int(kcol), _i(vmat, "vcache"),
             _f(vlut_rows, "lookup_table"), _f(vlut_sorted, "lut"), vp, _f(voutl, "outliers"),
-            _i(vidx, "outlier_indices"), int(vcol), qp, kh, int(thr_k), H, hd, max_len, ws.data_ptr(),
-            ws.numel(), _stream()), "kvq_decode_prologue")
+            _i(vidx, "outlier_indices"), int(vcol), qp, kh, int(thr_k), H, hd, max_len,
+            *_mirror(koutl_t, kidx_t, thr_k, max_len), ws.data_ptr(), ws.numel(), _stream()), "kvq_decode_prologue")
     return ws
 
 
@@ -324,7 +336,7 @@ def score_k_prepared(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers=Non
 
 
 def score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices, inv_sqrt_hd,
-                             n_parts):
+                             n_parts, outliers_t=None, outlier_indices_t=None):
     """sparse score kernel (tables already in `ws`, accumulate = 0) that also writes the per-(head, tile)
     softmax partials; returns the partials buffer (a workspace: consume it before the next call)."""
     H, hd, max_len = _cache_dims(mat, bits)
@@ -333,6 +345,7 @@ def score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outl
         _lib.check(_L().kvq_score_k_prepared_softmax(
             bits, _i(mat, "mat"), _f(mul, "mul"), _f(lut, "lookup_table"), H, hd, int(L), max_len, float(theta),
             int(pos_offset), _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outliers.shape[1],
+            *_mirror(outliers_t, outlier_indices_t, outliers.shape[1] // 2, max_len),
             ws.data_ptr(), ws.numel(), float(inv_sqrt_hd), parts.data_ptr(), n_parts, _stream()),
             "kvq_score_k_prepared_softmax")
     return parts
@@ -353,7 +366,7 @@ def softmax_finish(scores, parts, n_parts, inv_sqrt_hd, sink_scores=None):
 
 
 def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices, inv_sqrt_hd,
-                    sink_scores=None):
+                    sink_scores=None, outliers_t=None, outlier_indices_t=None):
     """q.K^T (tables already in `ws`) + softmax: `mul` [1, H, L] receives the raw scores; returns
     (probs f32 [H, L] holding fp16 values, sink_probs f16 [H, n_sink] or None).  Sparse caches take the
     score kernel with the first softmax pass fused in (2 launches), others score_k_prepared +
@@ -363,5 +376,5 @@ def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, out
         score_k_prepared(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices)
         return softmax_scale(mul[0], inv_sqrt_hd, sink_scores)
     parts = score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices,
-                                     inv_sqrt_hd, n_parts)
+                                     inv_sqrt_hd, n_parts, outliers_t, outlier_indices_t)
     return softmax_finish(mul[0], parts, n_parts, inv_sqrt_hd, sink_scores)

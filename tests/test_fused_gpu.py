@@ -68,6 +68,9 @@ def test_fused_decode_matches_oracle(gpu, bits, sinks):
     assert torch.equal(ov.outlier_indices[:L], gv.outlier_indices[:L].cpu())
     assert torch.equal(ov.outliers[:L].view(torch.int32), gv.outliers[:L].cpu().view(torch.int32))
     assert torch.equal(ov.lookup_table[:L].view(torch.int32), gv.lookup_table[:L].cpu().view(torch.int32))
+    # the token-contiguous mirror the decode kernel reads is the transpose of the reference-layout rows
+    assert torch.equal(gk.outlier_indices_t[:, :L].t().cpu(), gk.outlier_indices[:L].cpu())
+    assert torch.equal(gk.outliers_t[:, :L].t().cpu().view(torch.int32), gk.outliers[:L].cpu().view(torch.int32))
 
 
 def test_fused_selection_with_ties(gpu):
@@ -151,3 +154,12 @@ def test_score_softmax_fused_matches_two_pass(gpu, bits, L, n_sink):
     ck.score_k(bits, q, mat, ref, lut, L, 10000.0, 0)
     ck.spmv_k_rope(vals, idx, q, ref, L, 10000.0, 0)
     assert util.rel_err(s1.cpu().reshape(1, -1), ref.reshape(1, -1)) < 2e-5
+    # the same through the token-contiguous outlier mirror (lane-owns-token variant of the kernel)
+    vt, it = vg.t().contiguous(), ig.t().contiguous()
+    s3 = torch.zeros(1, H, L, device=gpu)
+    p3, sp3 = ops.score_k_softmax(bits, mg, s3, lg, L, 10000.0, 0, ws, vg, ig, inv, sink, vt, it)
+    assert util.rel_err(s3.cpu().reshape(1, -1), ref.reshape(1, -1)) < 2e-5
+    d = (p3 - p2).abs()
+    assert bool((d <= p2.abs() * 2e-3 + 1e-7).all()), float(d.max())
+    if n_sink:
+        assert bool(((sp3.float() - sp2.float()).abs() <= sp2.float().abs() * 2e-3 + 1e-7).all())
