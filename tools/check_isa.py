@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Static check of the built score kernels: registers written by the hand-issued (inline asm,
 not scoreboarded by hipcc) global loads must not be read, copied, spilled or overwritten before
-the next `s_waitcnt vmcnt(...)`.  hipcc knows nothing about those loads being in flight, so a
+a `s_waitcnt vmcnt(N)` that covers the load (N <= number of younger loads).  The scan follows the
+program text (the head loop is unrolled by its register sets, so the text order is the execution order
+of consecutive heads); it is a tripwire for bad register allocation, not a proof.  hipcc knows nothing about those loads being in flight, so a
 register move or spill it inserts in that window would capture stale data.
 
 usage: python tools/check_isa.py [file.s]   (default: compiles kvquant_amd/csrc/kvq_score_k.hip
@@ -62,6 +64,7 @@ def check(path, kernel_substr="score_k_kernel"):
                 continue
             dest = (lm.group(1), int(lm.group(2)))
             asm2 = False
+            younger = 0
             for ln2 in body[k + 1:]:
                 if "#ASMSTART" in ln2:
                     asm2 = True
@@ -72,8 +75,15 @@ def check(path, kernel_substr="score_k_kernel"):
                 code = ln2.split(";")[0].strip()
                 if not code or code.endswith(":") or code.startswith("."):
                     continue
-                if code.startswith("s_waitcnt") and "vmcnt(" in code:
-                    break
+                wm = re.search(r"vmcnt\((\d+)\)", code) if code.startswith("s_waitcnt") else None
+                if wm:
+                    # vmcnt(N) leaves at most the N youngest operations outstanding and loads return in order
+                    # among themselves (stores may overtake them, so only younger LOADS count)
+                    if younger >= int(wm.group(1)):
+                        break
+                    continue
+                if re.match(r"(global|buffer|scratch|flat)_load", code):
+                    younger += 1
                 if code.startswith("s_branch"):       # straight-line path ends (what follows is another path)
                     break
                 if dest in regs_of(code):
