@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: tools/pmc_run.sh <tag> <python script + args...>   (run on the GPU box; one rocprofv3 pass per counter set)
+# usage: tools/pmc_run.sh <tag> <python script + args...>   (run on the GPU box; one rocprofv3 pass per counter set;
+# raw counter CSVs go to $PMC_OUT (default /tmp: gpurun_out is capped at 64 MiB), the per-kernel summary to stdout)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 sets=(
@@ -10,7 +11,7 @@ sets=(
 )
 i=0
 for s in "${sets[@]}"; do
-  rocprofv3 --pmc $s --output-format csv -d gpurun_out/pmc_${tag}_$i -o p -- "$@" > gpurun_out/pmc_${tag}_$i.log 2>&1
+  rocprofv3 --pmc $s --output-format csv -d ${PMC_OUT:-/tmp}/pmc_${tag}_$i -o p -- "$@" > ${PMC_OUT:-/tmp}/pmc_${tag}_$i.log 2>&1
   i=$((i+1))
 done
-python tools/pmc_summary.py gpurun_out/pmc_${tag}_ $i
+python tools/pmc_summary.py ${PMC_OUT:-/tmp}/pmc_${tag}_ $i
