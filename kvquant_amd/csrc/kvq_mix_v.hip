@@ -37,6 +37,9 @@
 #include "kvq_mix_v_rows.h"
 
 #include <cstdlib>
+#ifndef KVQ_V_DBG
+#define KVQ_V_DBG 0
+#endif
 
 namespace kvq {
 
@@ -82,7 +85,7 @@ struct MixArgs {
   int n_units;
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out)
-  int dbg;                 // development only: 1 = skip math, 2 = skip DMA
+  int dbg;                 // development only (compile with -DKVQ_V_DBG=n): 1 skip math, 2 skip DMA, 4 DMA from L2
 };
 
 // Per-lane constants of the chunk DMA.  Every tile DMA instruction of a wave moves 64/QR consecutive
@@ -545,7 +548,7 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
   a.n_units = 0;
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
-  a.dbg = getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0;
+  a.dbg = KVQ_V_DBG;
   switch (bits) {
     case 4: return launch_mix<4>(a, mul, accumulate, st);
     case 3: return launch_mix<3>(a, mul, accumulate, st);

@@ -36,7 +36,10 @@
 #include "kvq_ktab.h"
 
 #ifndef KVQ_ABL
-#define KVQ_ABL 0
+#define KVQ_ABL 0      // ablation builds (tools/abl): timing experiments, results are wrong by construction
+#endif
+#ifndef KVQ_K_TMASK
+#define KVQ_K_TMASK (-1)   // development: AND-mask on the token of the packed-word loads (L2-resident source)
 #endif
 #include <cmath>
 #include <cstdlib>
@@ -673,7 +676,7 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.accumulate = accumulate;
-  a.dbg_tmask = getenv("KVQ_DBG_TMASK") ? atoi(getenv("KVQ_DBG_TMASK")) : -1;
+  a.dbg_tmask = KVQ_K_TMASK;
   a.sm_parts = sm_parts;
   a.sm_inv = sm_inv;
   a.sm_nparts = sm_nparts;

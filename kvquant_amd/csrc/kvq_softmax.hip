@@ -93,14 +93,33 @@ __global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restri
                                                             float inv, int nsplit, int n_parts, int sinks_in_parts) {
   __shared__ float red[2 * (NT / 64)];
   const int h = blockIdx.y, sp = blockIdx.x;
+  const int64_t per = ((L + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
+  const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
+  const float *row = scores + (int64_t)h * L;
+  float *out = probs + (int64_t)h * L;
+  // The slice's scores are requested BEFORE the (max, sum) merge of the row's partials, so that the two
+  // memory round trips overlap: up to PRE 16-byte loads per lane are in flight during the merge.
+  constexpr int PRE = 4;
+  const bool vec = ((reinterpret_cast<uintptr_t>(row) ^ reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  int64_t ta = t0 + ((4 - (int64_t)(((reinterpret_cast<uintptr_t>(row) >> 2) + (uint64_t)t0) & 3)) & 3);
+  if (ta > t1) ta = t1;
+  const int64_t tv = ta + threadIdx.x * 4;      // this lane's first vector element
+  float4 pre[PRE];
+  if (vec) {
+#pragma unroll
+    for (int k = 0; k < PRE; k++) {
+      const int64_t t = tv + (int64_t)k * NT * 4;
+      pre[k] = (t + 3 < t1) ? *reinterpret_cast<const float4 *>(row + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   // (max, sum) of the whole row from its n_parts partials (+ the sink scores when the producer of the
   // partials did not see them): per-lane online merge, then across the block
   float M = -INFINITY, Z = 0.f;
   for (int i = threadIdx.x; i < n_parts; i += NT) {
-    const float mi = ws[((int64_t)h * n_parts + i) * 2], si = ws[((int64_t)h * n_parts + i) * 2 + 1];
-    if (mi > -INFINITY) {
-      const float mn = fmaxf(M, mi);
-      Z = Z * expf(M - mn) + si * expf(mi - mn);   // (M = -inf: Z = 0)
+    const float2 ms = *reinterpret_cast<const float2 *>(ws + ((int64_t)h * n_parts + i) * 2);
+    if (ms.x > -INFINITY) {
+      const float mn = fmaxf(M, ms.x);
+      Z = Z * expf(M - mn) + ms.y * expf(ms.x - mn);   // (M = -inf: Z = 0)
       M = mn;
     }
   }
@@ -112,23 +131,16 @@ __global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restri
       M = mn;
     }
   block_merge<NT / 64>(M, Z, red);
-  const int64_t per = ((L + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
-  const int64_t t0 = sp * per, t1 = (t0 + per < L) ? (t0 + per) : L;
-  const float *row = scores + (int64_t)h * L;
-  float *out = probs + (int64_t)h * L;
   auto f = [&](float x) { return __half2float(__float2half_rn(expf(scaled(x, inv) - M) / Z)); };
-  if (((reinterpret_cast<uintptr_t>(row) ^ reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
-    int64_t ta = t0 + ((4 - (int64_t)(((reinterpret_cast<uintptr_t>(row) >> 2) + (uint64_t)t0) & 3)) & 3);
-    if (ta > t1) ta = t1;
+  if (vec) {
     if ((int64_t)threadIdx.x < ta - t0) out[t0 + threadIdx.x] = f(row[t0 + threadIdx.x]);
-    int64_t t = ta + threadIdx.x * 4;
-    for (; t + 3 * NT * 4 + 3 < t1; t += 4 * NT * 4) {   // four independent 16-byte loads in flight per lane
-      float4 v[4];
+    int64_t t = tv;
 #pragma unroll
-      for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const float4 *>(row + t + k * NT * 4);
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        *reinterpret_cast<float4 *>(out + t + k * NT * 4) = make_float4(f(v[k].x), f(v[k].y), f(v[k].z), f(v[k].w));
+    for (int k = 0; k < PRE; k++) {
+      if (t + 3 < t1) {
+        *reinterpret_cast<float4 *>(out + t) = make_float4(f(pre[k].x), f(pre[k].y), f(pre[k].z), f(pre[k].w));
+        t += NT * 4;
+      }
     }
     for (; t + 3 < t1; t += NT * 4) {
       const float4 v = *reinterpret_cast<const float4 *>(row + t);
