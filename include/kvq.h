@@ -156,6 +156,22 @@ KVQ_API int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows,
                        int32_t *outlier_idx, int thr_k, int H, int hd,
                        int64_t max_len, int64_t col, void *stream);
 
+/* Prefill forms of the two fused appends: S prompt tokens in ONE launch (one workgroup
+ * per token), replacing vecquant{b}appendvec{K,V}sparseParallel + the torch.topk /
+ * gather / sort glue of QuantK/QuantV.parallel_pack (modeling_llama.py:879-972,
+ * 1294-1382).  x: the prompt channel-major, float [H*hd][S] (KCPP:48-53); columns
+ * col0 .. col0+S-1 of the cache (must be zero) and rows col0.. of the outlier buffers
+ * (and of the optional K mirror) are written. */
+KVQ_API int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_off,
+                     const float *x, const float *lo, const float *hi, float *outliers,
+                     int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
+                     int64_t col0, int64_t S, float *outliers_t, int32_t *outlier_idx_t,
+                     void *stream);
+KVQ_API int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted,
+                     const float *x, float *outliers, int32_t *outlier_idx, int thr_k,
+                     int H, int hd, int64_t max_len, int64_t col0, int64_t S,
+                     void *stream);
+
 /* modeling_llama.py:873-874, 1950-1962, 1972-1977 in two launches: scores fp32
  * [H][L] (raw q.K^T) -> half -> * inv_sqrt_hd (fp16) -> softmax in fp32 over
  * [sink_scores | scores] -> fp16.  probs: the fp16 values widened to fp32, [H][L]

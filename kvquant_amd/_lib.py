@@ -29,6 +29,8 @@ SIGNATURES = {
     "kvq_mix_v": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_append_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _vp]),
     "kvq_append_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "kvq_pack_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "kvq_pack_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "kvq_softmax_workspace_bytes": (_sz, [_i, _i64]),
     "kvq_softmax_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp, _sz, _vp]),
     "kvq_decode_prologue": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,

@@ -189,15 +189,23 @@ class QuantK(nn.Module):
         mul = self.append_and_score(q, k)
         return mul.transpose(0, 1).contiguous().half()
 
-    def parallel_pack(self, k):
+    def parallel_pack(self, k, fused=True):
         """ML:879-972.  k: [H, hd, S] pre-RoPE keys of the prompt; the cache must
-        be empty (as in the reference, which writes columns 0..S-1)."""
+        be empty (as in the reference, which writes columns 0..S-1).  fused=False keeps the reference's
+        structure (pack kernel + torch top-k / gather / sort on the GPU)."""
         if not self.include_sparse:
             raise AssertionError("parallel_pack needs include_sparse (as the reference, ML:975)")
         k = k.float().contiguous()
         S = k.shape[-1]
         col0 = self.klen
         self.klen += S
+        if fused:
+            # one launch: pack + exact top-k selection + outlier rows (+ mirror), one workgroup per token
+            lut_off = self.lookup_table2 if self.norm else self.lookup_table
+            ops.pack_k_fused(self.bits, self.kcache, self.lookup_table, lut_off, k, self.outlier_threshold_lower,
+                             self.outlier_threshold_upper, self.outliers, self.outlier_indices,
+                             self.num_outliers // 2, col0, self.outliers_t, self.outlier_indices_t)
+            return
         resc = torch.empty_like(k)
         ops.pack_k_sparse_parallel(self.bits, self.kcache, self.lookup_table, k, resc,
                                    self.outlier_threshold_lower, self.outlier_threshold_upper, col0)
@@ -424,6 +432,11 @@ class QuantV(nn.Module):
         S = v.shape[-1]
         col0 = self.vlen
         self.vlen += S
+        if upper_outlier_vals is None and not self.norm:
+            # one launch: top-(k+1) selection, per-token codebook rows, pack, outlier rows
+            ops.pack_v_fused(self.bits, self.vcache, self.lookup_table, self.lut, v, self.outliers,
+                             self.outlier_indices, self.num_outliers // 2, col0)
+            return
         if upper_outlier_vals is None:
             vt = v.reshape(-1, S).t().contiguous()
             upper_outlier_vals, upper_outlier_indices, lower_outlier_vals, lower_outlier_indices = \

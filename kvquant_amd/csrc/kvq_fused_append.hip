@@ -136,8 +136,9 @@ struct AppendArgs {
   const float *lut_off;    // K: table the residuals refer to (lut, or the Q-Norm table)
   float *lut_rows;         // V: [max_len][N], row `col` is written
   const float *lut_sorted; // V: [N]
-  const void *x;           // [C], fp32 or fp16
+  const void *x;           // element of channel c: x[c * x_stride] (fp32 or fp16); decode: [C], stride 1
   int x_is_half;
+  int64_t x_stride;        // prefill pack: channel-major [C][S] input, stride S, x points at the token's column
   const float *lo, *hi;    // K thresholds
   float *outliers;
   int32_t *outlier_idx;
@@ -178,7 +179,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
 #pragma unroll
   for (int e = 0; e < E; e++) {
     ok[e] = e < per && (c0 + e) < C;
-    xv[e] = ok[e] ? ld_act(A.x, c0 + e, A.x_is_half) : 0.f;
+    xv[e] = ok[e] ? ld_act(A.x, (int64_t)(c0 + e) * A.x_stride, A.x_is_half) : 0.f;
   }
   if constexpr (!IS_V) {
 #pragma unroll
@@ -331,6 +332,18 @@ __global__ __launch_bounds__(kSelThreads) void fused_append_kernel(AppendArgs A)
   fused_append_body<BITS, IS_V>(A);
 }
 
+// Prefill: the same body, one workgroup per prompt token (the reference runs torch.topk over [S, C] and ~10
+// elementwise launches around its pack kernel, modeling_llama.py:879-972 / 1294-1382).  The prompt arrives
+// channel-major [C][S] (KCPP:48-53): token s reads a column, 4-byte elements S apart -- the 64-byte sectors
+// are shared by 16 neighbouring tokens and come out of L2 / the Infinity Cache for all but the first.
+template <int BITS, bool IS_V>
+__global__ __launch_bounds__(kSelThreads) void fused_pack_kernel(AppendArgs A) {
+  const int64_t s = blockIdx.x;
+  A.col += s;
+  A.x = reinterpret_cast<const float *>(A.x) + s;   // (fp32 prompt)
+  fused_append_body<BITS, IS_V>(A);
+}
+
 // Decode prologue of one layer in ONE launch: workgroup 0 = K fused append, 1 = V fused append,
 // 2.. = query-premultiplied K codebook images (one head each) for kvq_score_k_prepared.  The three jobs
 // are independent; run back to back they cost 27 + 16 + 4 us of mostly latency.
@@ -381,6 +394,7 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
   AppendArgs a;
   a.outliers_t = outliers_t;
   a.outlier_idx_t = idx_t;
+  a.x_stride = 1;
   a.mat = reinterpret_cast<uint32_t *>(mat);
   a.lut = lut;
   a.lut_off = lut_off;
@@ -427,6 +441,45 @@ int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut
                        int64_t col, void *stream) {
   return launch_fused<true>(bits, v_args(mat, lut_rows, lut_sorted, x, 0, outliers, outlier_idx, thr_k, H, hd,
                                          max_len, col), H, hd, (hipStream_t)stream);
+}
+
+static int launch_pack(bool is_v, int bits, AppendArgs a, int H, int hd, int64_t S, hipStream_t st) {
+  if (S <= 0 || a.col + S > a.max_len) return KVQ_EINVAL;
+  int rc = check_append(is_v, a, H, hd);
+  if (rc) return rc;
+  a.x_stride = S;
+  dim3 grid((unsigned)S), block(kSelThreads);
+  if (is_v) {
+    switch (bits) {
+      case 4: fused_pack_kernel<4, true><<<grid, block, 0, st>>>(a); break;
+      case 3: fused_pack_kernel<3, true><<<grid, block, 0, st>>>(a); break;
+      case 2: fused_pack_kernel<2, true><<<grid, block, 0, st>>>(a); break;
+      default: return KVQ_EINVAL;
+    }
+  } else {
+    switch (bits) {
+      case 4: fused_pack_kernel<4, false><<<grid, block, 0, st>>>(a); break;
+      case 3: fused_pack_kernel<3, false><<<grid, block, 0, st>>>(a); break;
+      case 2: fused_pack_kernel<2, false><<<grid, block, 0, st>>>(a); break;
+      default: return KVQ_EINVAL;
+    }
+  }
+  return check_launch();
+}
+
+int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_off, const float *x,
+                     const float *lo, const float *hi, float *outliers, int32_t *outlier_idx, int thr_k, int H,
+                     int hd, int64_t max_len, int64_t col0, int64_t S, float *outliers_t, int32_t *outlier_idx_t,
+                     void *stream) {
+  return launch_pack(false, bits, k_args(mat, lut, lut_off, x, 0, lo, hi, outliers, outlier_idx, thr_k, H, hd,
+                                         max_len, col0, outliers_t, outlier_idx_t), H, hd, S, (hipStream_t)stream);
+}
+
+int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
+                     float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
+                     int64_t col0, int64_t S, void *stream) {
+  return launch_pack(true, bits, v_args(mat, lut_rows, lut_sorted, x, 0, outliers, outlier_idx, thr_k, H, hd,
+                                        max_len, col0), H, hd, S, (hipStream_t)stream);
 }
 
 int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klut_off, const void *k,

@@ -199,6 +199,35 @@ def append_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices
                                            int(col), _stream()), "kvq_append_v_fused")
 
 
+def pack_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, thr_k, col0, outliers_t=None,
+                 outlier_indices_t=None):
+    """prefill: x f32 [H, hd, S] (channel-major prompt) -> columns col0.. of the cache + outlier rows, one launch."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    S = x.shape[-1]
+    if x.numel() != H * hd * S:
+        raise ValueError("x must be [H, hd, S]")
+    with _Dev(mat):
+        _lib.check(_L().kvq_pack_k_fused(bits, _i(mat, "mat"), _f(lut, "lookup_table"), _f(lut_off, "lut_off"),
+                                         _f(x, "newvec"), _f(lo, "lower"), _f(hi, "upper"),
+                                         _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"),
+                                         int(thr_k), H, hd, max_len, int(col0), int(S),
+                                         *_mirror(outliers_t, outlier_indices_t, thr_k, max_len), _stream()),
+                   "kvq_pack_k_fused")
+
+
+def pack_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col0):
+    """prefill: x f32 [H, hd, S] -> cache columns, per-token codebook rows and outlier rows, one launch."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    S = x.shape[-1]
+    if x.numel() != H * hd * S:
+        raise ValueError("x must be [H, hd, S]")
+    with _Dev(mat):
+        _lib.check(_L().kvq_pack_v_fused(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"), _f(lut_sorted, "lut"),
+                                         _f(x, "newvec"), _f(outliers, "outliers"),
+                                         _i(outlier_indices, "outlier_indices"), int(thr_k), H, hd, max_len,
+                                         int(col0), int(S), _stream()), "kvq_pack_v_fused")
+
+
 def softmax_scale(scores, inv_sqrt_hd, sink_scores=None):
     """scores: f32 [H, L] raw q.K^T; sink_scores: f16 [H, n_sink] already scaled, or None.
     Returns (probs f32 [H, L] holding fp16-rounded values, sink_probs f16 [H, n_sink] or None)."""

@@ -12,3 +12,39 @@ def test_decode_kv_matches_reference_pipeline(bits, prefill, steps, max_len):
         pytest.skip("no GPU")
     err = decode_check.run(torch.device("cuda:0"), bits=bits, prefill=prefill, steps=steps, max_len=max_len)
     assert err < 2e-3
+
+
+@pytest.mark.parametrize("bits", [4, 3, 2])
+def test_fused_prefill_pack_matches_reference_structure(bits):
+    """kvq_pack_{k,v}_fused (one launch for the whole prompt) against the reference-structured prefill
+    (pack kernel + torch.topk / gather / sort on the GPU): bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd.cache import QuantK, QuantV
+    dev = torch.device("cuda:0")
+    H, HD, C = decode_check.H, decode_check.HD, decode_check.C
+    S, max_len = 200, 256
+    quant, scale, shift = decode_check.quantizer(bits, seed=7 + bits)
+    g = torch.Generator().manual_seed(100 + bits)
+    k = (torch.randn(C, S, generator=g) * scale[:, None] * 1.3 + shift[:, None]).reshape(H, HD, S).to(dev)
+    v = (torch.randn(C, S, generator=g) * 1.7).reshape(H, HD, S).to(dev)
+    kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+              sparsity_threshold=0.99, first_few_fp16=0, device=dev)
+    ka, kb = QuantK(rope_theta=10000.0, **kw), QuantK(rope_theta=10000.0, **kw)
+    va, vb = QuantV(**kw), QuantV(**kw)
+    for c in (ka, kb, va, vb):
+        c.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+    ka.parallel_pack(k)                      # fused
+    kb.parallel_pack(k, fused=False)         # pack kernel + torch glue
+    assert torch.equal(ka.kcache, kb.kcache)
+    assert torch.equal(ka.outlier_indices, kb.outlier_indices)
+    assert torch.equal(ka.outliers.view(torch.int32), kb.outliers.view(torch.int32))
+    assert torch.equal(ka.outlier_indices_t, kb.outlier_indices_t)
+    assert torch.equal(ka.outliers_t.view(torch.int32), kb.outliers_t.view(torch.int32))
+    va.parallel_pack(v)                      # fused
+    vt = v.reshape(-1, S).t().contiguous()
+    vb.parallel_pack(v, *vb.topk_inputs(vt))
+    assert torch.equal(va.vcache, vb.vcache)
+    assert torch.equal(va.lookup_table.view(torch.int32), vb.lookup_table.view(torch.int32))
+    assert torch.equal(va.outlier_indices, vb.outlier_indices)
+    assert torch.equal(va.outliers.view(torch.int32), vb.outliers.view(torch.int32))
