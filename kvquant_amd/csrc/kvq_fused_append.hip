@@ -139,6 +139,7 @@ struct AppendArgs {
   const void *x;           // element of channel c: x[c * x_stride] (fp32 or fp16); decode: [C], stride 1
   int x_is_half;
   int64_t x_stride;        // prefill pack: channel-major [C][S] input, stride S, x points at the token's column
+  int codes_elsewhere;     // K in the decode prologue: the per-head table workgroups quantize and pack the token
   const float *lo, *hi;    // K thresholds
   float *outliers;
   int32_t *outlier_idx;
@@ -203,11 +204,12 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   // in play.
   float end_lo[E], end_hi[E];
   const bool same_tab = lut_off == lut;
+  const bool own_codes = IS_V || !A.codes_elsewhere;
   if constexpr (!IS_V) {
 #pragma unroll
     for (int e = 0; e < E; e++) {
       end_lo[e] = end_hi[e] = 0.f;
-      if (!ok[e]) continue;
+      if (!ok[e] || !own_codes) continue;
       float row[N];
       const float *src = lut + (int64_t)(c0 + e) * N;
 #pragma unroll
@@ -299,8 +301,9 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
       const int c = c0 + e;
       // residual to the saturated end point; zero when the rescaled value is inside [-1, 1]
       // (modeling_llama.py:729-747)
-      if (in_hi[e]) val = (sel[e] <= 1.0f) ? 0.f : xv[e] - (same_tab ? end_hi[e] : lut_off[(int64_t)c * N + (N - 1)]);
-      else val = (sel[e] >= -1.0f) ? 0.f : xv[e] - (same_tab ? end_lo[e] : lut_off[(int64_t)c * N]);
+      const bool have_ends = same_tab && own_codes;
+      if (in_hi[e]) val = (sel[e] <= 1.0f) ? 0.f : xv[e] - (have_ends ? end_hi[e] : lut_off[(int64_t)c * N + (N - 1)]);
+      else val = (sel[e] >= -1.0f) ? 0.f : xv[e] - (have_ends ? end_lo[e] : lut_off[(int64_t)c * N]);
     }
     if ((int)pos < n_out) {
       orow[pos] = val;
@@ -316,6 +319,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   }
 
   // ---- pack: one lane per 32-channel group ------------------------------------------------------------
+  if (!own_codes) return;
   for (int g = tid; g < C / 32; g += kSelThreads) {
     unsigned cd[32];
 #pragma unroll
@@ -357,11 +361,50 @@ struct PrologueArgs {
   int H;
 };
 
+// codes + pack of head h of the new K token (vecquant{b}appendvecK semantics, KCU:1202-1245 ...): the per-head
+// table workgroups read their head's codebook anyway, and it takes the 256 KB codebook read and the
+// nearest-code search off the single selection workgroup, which is the critical path of the prologue.
+template <int BITS>
+__device__ __forceinline__ void quantize_head(const AppendArgs &A, int h) {
+  constexpr int N = Fmt<BITS>::kN;
+  __shared__ unsigned hcodes[kHeadDim];
+  const int tid = threadIdx.x;
+  if (tid < kHeadDim) {
+    const int c = h * kHeadDim + tid;
+    const float x = ld_act(A.x, c, A.x_is_half);
+    float row[N];
+    const float *src = A.lut + (int64_t)c * N;
+#pragma unroll
+    for (int v = 0; v < N; v += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(src + v);
+      row[v] = t.x; row[v + 1] = t.y; row[v + 2] = t.z; row[v + 3] = t.w;
+    }
+    hcodes[tid] = nearest_code<N>(row, x);
+  }
+  __syncthreads();
+  if (tid < kHeadDim / 32) {
+    unsigned cd[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) cd[i] = hcodes[tid * 32 + i];
+    uint32_t w[BITS];
+    pack32<BITS>(cd, w);
+    const int g = h * (kHeadDim / 32) + tid;
+#pragma unroll
+    for (int i = 0; i < BITS; i++) A.mat[((int64_t)g * BITS + i) * A.max_len + A.col] = w[i];
+  }
+}
+
 template <int BITS>
 __global__ __launch_bounds__(kSelThreads) void decode_prologue_kernel(PrologueArgs P) {
-  if (blockIdx.x == 0) fused_append_body<BITS, false>(P.k);
-  else if (blockIdx.x == 1) fused_append_body<BITS, true>(P.v);
-  else lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.H, (int)blockIdx.x - 2, 0);
+  if (blockIdx.x == 0) {
+    fused_append_body<BITS, false>(P.k);
+  } else if (blockIdx.x == 1) {
+    fused_append_body<BITS, true>(P.v);
+  } else {
+    const int h = (int)blockIdx.x - 2;
+    quantize_head<BITS>(P.k, h);
+    lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.H, h, 0);
+  }
 }
 
 static int check_append(bool is_v, const AppendArgs &a, int H, int hd) {
@@ -395,6 +438,7 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
   a.outliers_t = outliers_t;
   a.outlier_idx_t = idx_t;
   a.x_stride = 1;
+  a.codes_elsewhere = 0;
   a.mat = reinterpret_cast<uint32_t *>(mat);
   a.lut = lut;
   a.lut_off = lut_off;
@@ -495,6 +539,7 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
   PrologueArgs P;
   P.k = k_args(kmat, klut, klut_off, k, acts_are_half, lo, hi, koutliers, kidx, thr_k, H, hd, max_len, kcol,
                koutliers_t, kidx_t);
+  P.k.codes_elsewhere = 1;   // (hd == 128 here: one table workgroup per head covers every channel)
   P.v = v_args(vmat, vlut_rows, vlut_sorted, v, acts_are_half, voutliers, vidx, thr_k, H, hd, max_len, vcol);
   int rc = check_append(false, P.k, H, hd);
   if (rc) return rc;
