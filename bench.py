@@ -171,13 +171,15 @@ def cpu_baseline(bits, sample_tokens, ctx, layers):
     while True:
         ck.sim_decode_step(khat, vhat, q, H, HD, THETA, 0)
         reps += 1
-        if time.time() - t0 > 10.0 or reps >= 20:
+        if time.time() - t0 > 10.0 or reps >= 2000:   # a bounded ~10 s sample of CPU work
             break
-    dt = (time.time() - t0) / reps
+    total = time.time() - t0
+    dt = total / reps
     step_s = dt * (ctx / sample_tokens) * layers
     return {"value": 1.0 / step_s, "unit": "tokens/s", "cores": ck.num_threads(), "kind": "port",
-            "sample": "1 layer x %d reconstructed tokens (fp32 RoPE+qK^T+softmax+pV, oracle C/OpenMP), %.3f s, "
-                      "scaled x%g tokens x%d layers" % (sample_tokens, dt, ctx / sample_tokens, layers)}
+            "sample": "%d x (1 layer x %d reconstructed tokens: fp32 RoPE+qK^T+softmax+pV, oracle C/OpenMP) = %.1f s of "
+                      "CPU work, %.3f s each, scaled x%g tokens x%d layers"
+                      % (reps, sample_tokens, total, dt, ctx / sample_tokens, layers)}
 
 
 def main():
