@@ -52,7 +52,7 @@ struct VCfg {
   static constexpr int NT = 512;                       // threads per workgroup
   static constexpr int UW = BITS == 3 ? 128 : 256;     // units per workgroup
   static constexpr int SLOTS = NT / UW;                // token slots
-  static constexpr int CT = BITS == 3 ? 16 : 32;       // tokens per chunk
+  static constexpr int CT = BITS == 4 ? 32 : 16;       // tokens per chunk (2 bit: 32 needs ~200 VGPRs as unrolled)
   static constexpr int QR = CT / 4;                    // 16-byte quads per tile row
   static constexpr int SH = CT == 32 ? 1 : 2;          // log2(tile rows per 256 B)
   static constexpr int ROWS = UW * WORDS;              // tile rows
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
       const int cn = (C - c0 < SCH) ? (C - c0) : SCH;
       for (int i = tid; i < cn; i += Cfg::NT) sacc[i] = 0;
       __syncthreads();
-      constexpr int RB = 21;   // entries per lane per round (a 256-token share at n_out = 42 in one round);
+      constexpr int RB = BITS == 4 ? 21 : 7;   // entries per lane per round (a 256-token share at n_out = 42 in one round);
                                // loads are unconditional (clamped index) and issued back to back
       for (unsigned base = 0; base < nent; base += RB * Cfg::NT) {
         int row[RB];
@@ -349,6 +349,20 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
             const uint32_t off = (src >> (8 * (i / 2))) & 0xffu;
             acc[i] = fmaf(*reinterpret_cast<const float *>(row + off), pt, acc[i]);
           });
+        } else if constexpr (BITS == 2) {
+          // same idea at 2 bit: byte b of pre-masked word k holds code*4 (+ slot*16) of channel 4b + k
+          const uint32_t sp2 = (uint32_t)sl * 0x10101010u;
+          const uint32_t pk[4] = {((w[0] << 2) & 0x0C0C0C0Cu) | sp2, (w[0] & 0x0C0C0C0Cu) | sp2,
+                                  ((w[0] >> 2) & 0x0C0C0C0Cu) | sp2, ((w[0] >> 4) & 0x0C0C0C0Cu) | sp2};
+          const unsigned char *row = lutb + (qq * 4 + e) * Cfg::SLOTS * N * 4;
+          static_for<0, 2>([&](auto HF) {          // 8 look-ups in flight at a time
+            static_for<0, 8>([&](auto I) {
+              constexpr int i = decltype(HF)::value * 8 + decltype(I)::value;
+              const uint32_t off = (pk[i & 3] >> (8 * (i / 4))) & 0xffu;
+              acc[i] = fmaf(*reinterpret_cast<const float *>(row + off), pt, acc[i]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
         } else {
           const float *tab = reinterpret_cast<const float *>(lutb) + ((qq * 4 + e) * Cfg::SLOTS + sl) * N;
           static_for<0, CH>([&](auto I) {
@@ -356,8 +370,9 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
             acc[i] = fmaf(tab[vcode<BITS, i, WORDS>(w)], pt, acc[i]);
           });
         }
-        if constexpr (e & 1)
-          __builtin_amdgcn_sched_barrier(0);   // two tokens' (8..32 each) look-ups in flight at a time (VGPR budget)
+        if constexpr (CH > 8 || (e & 1))
+          __builtin_amdgcn_sched_barrier(0);   // 16 look-ups (two 4-bit tokens / one 2-bit token) or one 3-bit token's 32 in
+                                               // flight at a time (VGPR budget)
       });
     });
   };
