@@ -110,7 +110,9 @@ KVQ_API int kvq_pack_v_sparse_parallel(int bits, int32_t *mat, const float *lut_
  * mul: float [q_len][H][L].  accumulate != 0: add into mul (the reference's
  * pre-zeroed contract); 0: overwrite.  Needs a 16-byte aligned device workspace of
  * kvq_score_k_workspace_bytes(...) bytes (the query-premultiplied codebook
- * images, H * 2^bits KiB). */
+ * images, H * 2^bits KiB).  outlier_idx of a token in ascending order (as the
+ * reference's glue stores it) takes the fast path; any other order is still
+ * summed correctly, one entry at a time. */
 KVQ_API size_t kvq_score_k_workspace_bytes(int bits, int q_len, int H);
 KVQ_API int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul,
                 const float *lut, int q_len, int H, int hd, int64_t L,

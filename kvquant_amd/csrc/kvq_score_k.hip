@@ -282,6 +282,17 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
     float sum = use ? val * fmaf(c, q1, sg * q2) : 0.f;
     // run key = (token, TRUE head): a zeroed or foreign-group entry keeps its own head, it just carries 0
     const int key = in ? (int)(tle * 1024 + (unsigned)((col >> 7) & 1023)) : -1 - lane;
+    // The scan below needs equal (token, head) keys to be contiguous, i.e. a token's entries in ascending
+    // channel order -- which is how the reference's glue stores them (modeling_llama.py:742, 1171) but not
+    // something its kernel (one atomic per entry) depends on.  Any other order: one lane at a time.
+    {
+      const int kp = __shfl_up(key, 1);
+      if (__any(in && lane > 0 && kp >= 0 && kp > key)) {
+        for (int i = 0; i < 64; i++)
+          if (lane == i && use && sum != 0.f) sc[tle * SCS + ((hh + tle) & (SCS - 1))] += sum;
+        return;
+      }
+    }
 #if !(KVQ_ABL & 8)
     // runs are short (42 entries of a token over 32 heads: ~1.8 on average), so the scan stops as soon as
     // no lane has a run-mate d lanes below (keys are sorted inside a token: if nobody matches at distance

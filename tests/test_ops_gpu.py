@@ -206,3 +206,26 @@ def test_bad_arguments_raise(qc):
     from kvquant_amd._lib import KvqError
     with pytest.raises(KvqError):
         qc.vecquant4appendvecK(m, lut, torch.zeros(C).cuda(), 8)    # column out of range
+
+
+def test_score_k_unsorted_outlier_rows(qc, orc):
+    """the reference's SpMV is one atomic per entry and does not care about the order of a token's entries;
+    its glue happens to sort them, which the fast path exploits -- unsorted rows must still be right"""
+    bits, L = 4, 700
+    max_len = L + 4
+    lut, _, _, _, _ = util.k_tables(bits, seed=3)
+    mat = _random_cache(bits, L, max_len, 99)
+    g = torch.Generator().manual_seed(17)
+    q = torch.randn(1, H, HD, generator=g)
+    vals, idx = _outliers(L, max_len, 5)
+    perm = torch.stack([torch.randperm(42, generator=g) for _ in range(max_len)])
+    vals, idx = torch.gather(vals, 1, perm), torch.gather(idx, 1, perm)
+    # duplicates of one (token, head) far apart inside a row as well
+    idx[10, 0], idx[10, 41] = 5, 6
+    vals[10, 0], vals[10, 41] = 1.5, -2.5
+    ref = torch.zeros(1, H, L)
+    got = torch.zeros(1, H, L).cuda()
+    name = "vecquant4matmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt2"
+    getattr(orc, name)(q, mat, ref, lut, L, vals, idx, 10000.0, 0)
+    getattr(qc, name)(q.cuda(), mat.cuda(), got, lut.cuda(), L, vals.cuda(), idx.cuda(), 10000.0, 0)
+    assert util.rel_err(got.cpu().reshape(1, -1), ref.reshape(1, -1)) < TOL
