@@ -24,12 +24,20 @@
 //     a single v_bfe_u32; everything else is an instruction immediate (static
 //     LDS);
 //   * packed words are read with lanes along the token axis (the contiguous
-//     axis): 128 B per half-wave per row, two heads ahead of the math;
-//   * the sparse residuals of the tile are scattered into an LDS score tile
-//     with ds_add_f32 before the dense loop (entries fetched in batches so the
-//     HBM latency is paid three times per tile, not once per entry) and folded
-//     into the single store of each score: no global atomics, one store per
-//     score (the reference does one atomic per outlier and one per score).
+//     axis): 128 B per half-wave per row, one head ahead of the math;
+//   * sparse residuals: the tile's scores collect in an LDS [token][head] tile
+//     (dense results and residuals alike) that is written out once -- no
+//     global atomics, one store per score (the reference does one atomic per
+//     outlier and one per score).  The residual work is spread over the head
+//     loop (one piece per head iteration, its loads one iteration ahead).
+//     Reference row layout [max_len][n_out]: 64-lane chunks of the wave's own
+//     tokens' entries, segmented wave scan over (token, head) runs.  Token-
+//     contiguous mirror [n_out][max_len] (kvquant_amd's own cache): a lane
+//     owns its token's entries, no scan;
+//   * the first softmax pass (max, sum exp of the fp16-scaled scores per head
+//     and tile) can be taken from the LDS tile before it is written out;
+//   * the ragged last tile is cut into short head-group workgroups so that it
+//     is a tail, not a second round of the grid.
 // Algorithmic HBM bytes per cached token: C*bits/8 (+ 8*n_out sparse) + 4*H.
 #include "kvq_common.h"
 #include "kvq_host.h"
