@@ -48,3 +48,39 @@ def test_fused_prefill_pack_matches_reference_structure(bits):
     assert torch.equal(va.lookup_table.view(torch.int32), vb.lookup_table.view(torch.int32))
     assert torch.equal(va.outlier_indices, vb.outlier_indices)
     assert torch.equal(va.outliers.view(torch.int32), vb.outliers.view(torch.int32))
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_k_qnorm_paths_match_oracle(bits):
+    """Q-Norm (load_lookup_table(norm=True), ML:486-497): the residuals refer to lookup_table2, and at 2 bit the
+    score kernel dequantises with it (ML:811-815).  Decode (fused append + score) and prefill pack vs the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd.cache import QuantK
+    from oracle.glue import OracleQuantK
+    from tests import util
+    dev = torch.device("cuda:0")
+    H, HD, C = decode_check.H, decode_check.HD, decode_check.C
+    quant, scale, shift = decode_check.quantizer(bits, seed=11 + bits)
+    quant = tuple(quant) + (1.07, -0.02)          # (upper, lower, [centroids], normscale, normoffset)
+    prefill, steps, max_len = 24, 3, 64
+    ks = util.k_tokens(prefill + steps, scale, shift, seed=60 + bits)
+    g = torch.Generator().manual_seed(70 + bits)
+    qs = torch.randn(steps, H, 1, HD, generator=g).half()
+    kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+              sparsity_threshold=0.99, first_few_fp16=0, rope_theta=10000.0)
+    ok, gk = OracleQuantK(**kw), QuantK(device=dev, **kw)
+    for c in (ok, gk):
+        c.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99, norm=True)
+    kp = ks[:prefill].half().float().t().reshape(H, HD, prefill).contiguous()
+    ok.parallel_pack(kp)
+    gk.parallel_pack(kp.to(dev))
+    for i in range(steps):
+        k16, q16 = ks[prefill + i].half(), qs[i]
+        s_ref = ok.forward_fused_sparse(q16, k16)
+        s_gpu = gk.forward_fused_sparse(q16.to(dev), k16.to(dev))
+        assert util.rel_err(s_gpu.float().cpu(), s_ref.float()) < 2e-3
+    L = prefill + steps
+    assert torch.equal(ok.kcache[:, :, :L], gk.kcache[:, :, :L].cpu())
+    assert torch.equal(ok.outlier_indices[:L], gk.outlier_indices[:L].cpu())
+    assert torch.equal(ok.outliers[:L].view(torch.int32), gk.outliers[:L].cpu().view(torch.int32))
