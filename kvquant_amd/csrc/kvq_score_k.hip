@@ -504,17 +504,25 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
       sparse_chunk(j, v, cidx);
     }
     if constexpr (TRANSPOSED) {
-      // entries beyond the number of heads of this workgroup (ragged-tile / small-group blocks): two at a
-      // time 
-      for (int s0 = nh; s0 < nsteps; s0 += 2) {
-        float v0, v1 = 0.f;
-        int c0i, c1i = 0;
-        sparse_fetch_t(s0, v0, c0i);
-        if (s0 + 1 < nsteps) sparse_fetch_t(s0 + 1, v1, c1i);
+      // entries beyond the number of heads of this workgroup (ragged-tile / small-group blocks): batches of
+      // TB, so that the memory latency is paid per batch (the registers of the dense loop are free here;
+      // fetch and wait are back to back, nothing can touch the destinations in between)
+      constexpr int TB = 7;
+      for (int s0 = nh; s0 < nsteps; s0 += TB) {
+        float v[TB];
+        int ci2[TB];
+#pragma unroll
+        for (int k = 0; k < TB; k++) {
+          v[k] = 0.f;
+          ci2[k] = 0;
+          if (s0 + k < nsteps) sparse_fetch_t(s0 + k, v[k], ci2[k]);
+        }
         vm_wait<0>();
-        asm volatile("" : "+v"(v0), "+v"(c0i), "+v"(v1), "+v"(c1i));   // (the values exist from here on)
-        sparse_step_t(s0, v0, c0i);
-        if (s0 + 1 < nsteps) sparse_step_t(s0 + 1, v1, c1i);
+#pragma unroll
+        for (int k = 0; k < TB; k++) asm volatile("" : "+v"(v[k]), "+v"(ci2[k]));   // (the values exist from here on)
+#pragma unroll
+        for (int k = 0; k < TB; k++)
+          if (s0 + k < nsteps) sparse_step_t(s0 + k, v[k], ci2[k]);
       }
     }
     // write the tile out: the two wave halves take alternate heads, 128 B per half-wave per head
