@@ -191,7 +191,10 @@ KVQ_API int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores,
  * kvq_score_k_prepared, as three roles of ONE launch (the jobs are independent and
  * latency-bound).  k, v: [H*hd], q: [H][128] (already RoPE'd), all fp32
  * (acts_are_half = 0) or all fp16 (1, the model's activation dtype: saves the
- * reference's three .float() launches).  score_workspace as for kvq_score_k. */
+ * reference's three .float() launches).  score_workspace as for kvq_score_k.
+ * klut_ends (optional): float [H*hd][2] = (klut_off[c][0], klut_off[c][2^bits-1]),
+ * the two codebook values the outlier residuals refer to, contiguous -- a constant
+ * of the layer that saves the selection workgroup a dependent 256 KB-strided read. */
 KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
                         const float *klut_off, const void *k, const float *lo,
                         const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
@@ -199,7 +202,8 @@ KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
                         const void *v, float *voutliers, int32_t *vidx, int64_t vcol,
                         const void *q, int acts_are_half, int thr_k, int H, int hd,
                         int64_t max_len, float *koutliers_t, int32_t *kidx_t,
-                        void *score_workspace, size_t score_workspace_bytes, void *stream);
+                        const float *klut_ends, void *score_workspace,
+                        size_t score_workspace_bytes, void *stream);
 /* kvq_score_k for q_len = 1 with the tables (and the fp32 query copy) already in
  * `workspace` (written by kvq_decode_prologue on the same stream). */
 KVQ_API int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const float *lut,

@@ -34,7 +34,7 @@ SIGNATURES = {
     "kvq_softmax_workspace_bytes": (_sz, [_i, _i64]),
     "kvq_softmax_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp, _sz, _vp]),
     "kvq_decode_prologue": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                 _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
+                                 _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kvq_score_k_prepared": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_score_k_softmax_parts": (_i, [_i, _i64, _i]),
     "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,

@@ -134,6 +134,9 @@ class QuantK(nn.Module):
             self.normscale = self.normoffset = None
             self.lookup_table2 = None
         self.zeropoint = ((up16 + lo16) / 2).float()
+        # the two codebook values the outlier residuals refer to (ML:729-733), contiguous per channel
+        t_off = self.lookup_table2 if norm else self.lookup_table
+        self.lut_ends = torch.stack((t_off[..., 0], t_off[..., -1]), dim=-1).reshape(-1, 2).contiguous()
         self.outlier_threshold_upper = up16.float().contiguous()
         self.outlier_threshold_lower = lo16.float().contiguous()
 
@@ -476,7 +479,7 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
                              kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
                              vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
-                             kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t)
+                             kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t, kc.lut_ends)
     kc.klen += 1
     vc.vlen += 1
     L = kc.klen - kc.first_few_fp16

@@ -140,6 +140,8 @@ struct AppendArgs {
   int x_is_half;
   int64_t x_stride;        // prefill pack: channel-major [C][S] input, stride S, x points at the token's column
   int codes_elsewhere;     // K in the decode prologue: the per-head table workgroups quantize and pack the token
+  const float *lut_ends;   // K, optional: [C][2] = (lut_off[c][0], lut_off[c][N-1]) contiguous, so that the
+                           // selection workgroup gets the residual end points without touching the codebook
   const float *lo, *hi;    // K thresholds
   float *outliers;
   int32_t *outlier_idx;
@@ -205,10 +207,16 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   float end_lo[E], end_hi[E];
   const bool same_tab = lut_off == lut;
   const bool own_codes = IS_V || !A.codes_elsewhere;
+  const bool pre_ends = !IS_V && A.lut_ends != nullptr;
   if constexpr (!IS_V) {
 #pragma unroll
     for (int e = 0; e < E; e++) {
       end_lo[e] = end_hi[e] = 0.f;
+      if (ok[e] && pre_ends) {
+        const float2 t = *reinterpret_cast<const float2 *>(A.lut_ends + 2 * (c0 + e));
+        end_lo[e] = t.x;
+        end_hi[e] = t.y;
+      }
       if (!ok[e] || !own_codes) continue;
       float row[N];
       const float *src = lut + (int64_t)(c0 + e) * N;
@@ -218,8 +226,10 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
         row[v] = t.x; row[v + 1] = t.y; row[v + 2] = t.z; row[v + 3] = t.w;
       }
       sh.codes[c0 + e] = nearest_code<N>(row, xv[e]);
-      end_lo[e] = row[0];
-      end_hi[e] = row[N - 1];
+      if (!pre_ends) {
+        end_lo[e] = row[0];
+        end_hi[e] = row[N - 1];
+      }
     }
   }
 
@@ -301,7 +311,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
       const int c = c0 + e;
       // residual to the saturated end point; zero when the rescaled value is inside [-1, 1]
       // (modeling_llama.py:729-747)
-      const bool have_ends = same_tab && own_codes;
+      const bool have_ends = pre_ends || (same_tab && own_codes);
       if (in_hi[e]) val = (sel[e] <= 1.0f) ? 0.f : xv[e] - (have_ends ? end_hi[e] : lut_off[(int64_t)c * N + (N - 1)]);
       else val = (sel[e] >= -1.0f) ? 0.f : xv[e] - (have_ends ? end_lo[e] : lut_off[(int64_t)c * N]);
     }
@@ -439,6 +449,7 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
   a.outlier_idx_t = idx_t;
   a.x_stride = 1;
   a.codes_elsewhere = 0;
+  a.lut_ends = nullptr;
   a.mat = reinterpret_cast<uint32_t *>(mat);
   a.lut = lut;
   a.lut_off = lut_off;
@@ -531,7 +542,8 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
                         int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
                         float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
                         int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
-                        void *score_workspace, size_t score_workspace_bytes, void *stream) {
+                        const float *klut_ends, void *score_workspace, size_t score_workspace_bytes,
+                        void *stream) {
   if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
   if (score_workspace_bytes < kvq_score_k_workspace_bytes(bits, 1, H) ||
       reinterpret_cast<uintptr_t>(score_workspace) % 16)
@@ -540,6 +552,7 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
   P.k = k_args(kmat, klut, klut_off, k, acts_are_half, lo, hi, koutliers, kidx, thr_k, H, hd, max_len, kcol,
                koutliers_t, kidx_t);
   P.k.codes_elsewhere = 1;   // (hd == 128 here: one table workgroup per head covers every channel)
+  P.k.lut_ends = klut_ends;
   P.v = v_args(vmat, vlut_rows, vlut_sorted, v, acts_are_half, voutliers, vidx, thr_k, H, hd, max_len, vcol);
   int rc = check_append(false, P.k, H, hd);
   if (rc) return rc;

@@ -330,7 +330,7 @@ def _act(t, name):
 
 
 def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vmat, vlut_rows, vlut_sorted, v,
-                    voutl, vidx, vcol, q, thr_k, koutl_t=None, kidx_t=None):
+                    voutl, vidx, vcol, q, thr_k, koutl_t=None, kidx_t=None, klut_ends=None):
     """K fused append + V fused append + K codebook images for score_k_prepared in ONE launch.
     q [H,128] (RoPE'd), k, v [C]: all fp32 or all fp16.  Returns the score workspace tensor."""
     H, hd, max_len = _cache_dims(kmat, bits)
@@ -347,7 +347,8 @@ def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vm
             _f(hi, "upper"), _f(koutl, "outliers"), _i(kidx, "outlier_indices"), int(kcol), _i(vmat, "vcache"),
             _f(vlut_rows, "lookup_table"), _f(vlut_sorted, "lut"), vp, _f(voutl, "outliers"),
             _i(vidx, "outlier_indices"), int(vcol), qp, kh, int(thr_k), H, hd, max_len,
-            *_mirror(koutl_t, kidx_t, thr_k, max_len), ws.data_ptr(), ws.numel(), _stream()), "kvq_decode_prologue")
+            *_mirror(koutl_t, kidx_t, thr_k, max_len), None if klut_ends is None else _f(klut_ends, "lut_ends"),
+            ws.data_ptr(), ws.numel(), _stream()), "kvq_decode_prologue")
     return ws
 
 
