@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--ctx", type=int, default=131072)
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--layers", type=int, default=N_LAYERS)
+    ap.add_argument("--sinks", type=int, default=0,
+                    help="first_few_fp16 attention-sink tokens kept in fp16 (BASELINE config 3: --bits 3 --sinks 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=16384)
     return ap.parse_args()
@@ -71,15 +73,24 @@ def synth_tokens(S, scale, shift, gen, dev):
 
 
 class Layer:
-    def __init__(self, bits, max_len, gen, dev):
+    def __init__(self, bits, max_len, gen, dev, sinks=0):
         from kvquant_amd.cache import QuantK, QuantV
         quant, self.scale, self.shift = synth_quantizer(bits, gen, dev)
         self.k = QuantK(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
-                        include_sparse=True, sparsity_threshold=0.99, rope_theta=THETA, device=dev)
+                        include_sparse=True, sparsity_threshold=0.99, rope_theta=THETA, first_few_fp16=sinks,
+                        device=dev)
         self.v = QuantV(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
-                        include_sparse=True, sparsity_threshold=0.99, device=dev)
+                        include_sparse=True, sparsity_threshold=0.99, first_few_fp16=sinks, device=dev)
         self.k.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
         self.v.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        self.sinks = sinks
+        if sinks:
+            # the first tokens stay in fp16 (post-RoPE keys), ML:1464-1466; their scores / outputs are two tiny
+            # fp16 matmuls around the compressed path, as in the reference (ML:1950-1962, 1987-1995)
+            self.k_sink = (torch.randn(H, HD, sinks, generator=gen, device=dev) * 0.5).half()
+            self.v_sink = torch.randn(H, sinks, HD, generator=gen, device=dev).half()
+            self.k.klen += sinks
+            self.v.vlen += sinks
 
     def fill(self, ctx, gen, dev, chunk=8192):
         done = 0
@@ -97,6 +108,12 @@ def decode_step(layers, qs, ks, vs, step):
     from kvquant_amd.cache import decode_kv
     out = None
     for li, lay in enumerate(layers):
+        if lay.sinks:
+            q = qs[li][step]
+            sink_scores = (torch.bmm(q.unsqueeze(1), lay.k_sink) / math.sqrt(HD)).squeeze(1)        # f16 [H, n_sink]
+            out, sp = decode_kv(lay.k, lay.v, q, ks[li][step], vs[li][step], sink_scores)
+            out = out + torch.bmm(sp.unsqueeze(1), lay.v_sink).transpose(0, 1).float()
+            continue
         out, _ = decode_kv(lay.k, lay.v, qs[li][step], ks[li][step], vs[li][step])   # f32 [1,H,hd]
     return out.half()
 
@@ -205,7 +222,7 @@ def main():
     t_setup = time.time()
     layers = []
     for li in range(args.layers):
-        lay = Layer(args.bits, max_len, gen, dev)
+        lay = Layer(args.bits, max_len, gen, dev, args.sinks)
         lay.fill(args.ctx, gen, dev)
         layers.append(lay)
     # per-layer decode inputs, resident before timing
@@ -268,8 +285,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LLaMA-2-7B KV path: H=32 hd=128 layers=%d nuq%d + 1%% outliers (42/token), "
-                                   "ctx=%d cached tokens, batch 1 per GPU" % (args.layers, args.bits, args.ctx),
-                       "ctx": args.ctx, "bits": args.bits, "layers": args.layers,
+                                   "ctx=%d cached tokens%s, batch 1 per GPU"
+                                   % (args.layers, args.bits, args.ctx,
+                                      " + %d fp16 attention-sink tokens" % args.sinks if args.sinks else ""),
+                       "ctx": args.ctx, "bits": args.bits, "layers": args.layers, "sinks": args.sinks,
                        "parallelism": "independent decode streams x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
