@@ -51,7 +51,13 @@ struct VCfg {
   static constexpr int UPH = kHeadDim / CH;            // units per head
   static constexpr int NT = 512;                       // threads per workgroup
   static constexpr int UW = BITS == 3 ? 128 : 256;     // units per workgroup
-  static constexpr int SLOTS = NT / UW;                // token slots
+  // 3 bit: a unit is 32 channels in 3 word-rows; two lanes ("halves", wave-uniform: lanes [0,UW) / [UW,2UW) of a
+  // slot) read the same three rows and decode 16 channels each -- 32 accumulators in one lane do not fit the
+  // 128-VGPR budget next to the look-ups in flight, and a spill inside the chunk loop makes hipcc drain the
+  // DMAs just issued
+  static constexpr int HALVES = BITS == 3 ? 2 : 1;
+  static constexpr int CHL = CH / HALVES;              // channels per lane
+  static constexpr int SLOTS = NT / (UW * HALVES);     // token slots
   static constexpr int CT = BITS == 4 ? 32 : 16;       // tokens per chunk (2 bit: 32 needs ~200 VGPRs as unrolled)
   static constexpr int QR = CT / 4;                    // 16-byte quads per tile row
   static constexpr int SH = CT == 32 ? 1 : 2;          // log2(tile rows per 256 B)
@@ -63,7 +69,7 @@ struct VCfg {
   static constexpr int P_B = HW * CT * 4;
   static constexpr int QPL = QR / SLOTS;               // quads per lane per chunk
   static constexpr int BUF_B = TILE_B + LUT_B + P_B;   // one pipeline stage
-  static constexpr int RED_B = NT * CH * 4;            // slot reduction (aliases the stages)
+  static constexpr int RED_B = NT * CHL * 4;           // slot reduction (aliases the stages)
   static constexpr int SMEM_B = (2 * BUF_B > RED_B ? 2 * BUF_B : RED_B);
   static_assert(QR % SLOTS == 0, "slots must split the chunk's quads");
 };
@@ -136,11 +142,14 @@ __device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, 
   constexpr int N_P = Cfg::P_B / 256;
   constexpr int K_P = (N_P + NW - 1) / NW;
   // ---- packed rows: uniform base per instruction, ONE 32-bit lane offset (bytes) for all of them
+  // (token clamps in 32-bit arithmetic relative to the chunk: wave-uniform 64-bit limits, 32-bit lane values --
+  // 64-bit per-lane compares cost VGPR pairs, and a spill in here makes hipcc drain the DMAs just issued)
+  const int lim_len = (int)(a.max_len - c0);   // tokens from the chunk start to the end of the rows (multiple of 4, >= 4)
+  const int lim_L = (int)(a.L - c0);           // ... to the end of the cache (>= 1)
   {
-    int64_t tok = c0 + d.tile_q4;
-    if (tok + 4 > a.max_len) tok = a.max_len - 4;
     const uint32_t *gbase = a.mat + (int64_t)row_base * a.max_len + c0;
-    const uint32_t toff = (uint32_t)(tok - c0);
+    const int tq = (int)d.tile_q4;
+    const uint32_t toff = (uint32_t)(tq + 4 > lim_len ? lim_len - 4 : tq);
 #pragma unroll
     for (int k = 0; k < K_TILE; k++) {
       const int j = wave + k * NW;
@@ -154,18 +163,15 @@ __device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, 
   }
   // ---- codebook rows of the chunk
   if ((int)threadIdx.x < LUT_SLOTS) {   // wave-granular: LUT_SLOTS is a multiple of 64 or < 64
-    int64_t t = c0 + d.lut_tok;
-    if (t >= a.max_len) t = a.max_len - 1;
+    const int tr2 = (int)d.lut_tok < lim_len ? (int)d.lut_tok : lim_len - 1;
     const float *gbase = a.lut_rows + c0 * Cfg::N;
-    const uint32_t voff = ((uint32_t)(t - c0) * Cfg::N + d.lut_sub) * 4u;
+    const uint32_t voff = ((uint32_t)tr2 * Cfg::N + d.lut_sub) * 4u;
     dma16(gbase, voff, buf + Cfg::TILE_B + wave * 1024);
   }
   // ---- probabilities of the workgroup's heads, 4 B per lane
   {
     const float *gbase = a.p + ((int64_t)b * a.H + h0) * a.L + c0;
-    int64_t t = c0 + d.p_tok;
-    if (t >= a.L) t = a.L - 1;
-    const uint32_t toff = (uint32_t)(t - c0);
+    const uint32_t toff = (uint32_t)((int)d.p_tok < lim_L ? (int)d.p_tok : lim_L - 1);
 #pragma unroll
     for (int k = 0; k < K_P; k++) {
       const int j = wave + k * NW;
@@ -195,7 +201,9 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
 
   const int tid = threadIdx.x;
   const int ul = tid % Cfg::UW;          // unit within the workgroup
-  const int sl = tid / Cfg::UW;          // token slot (wave-uniform)
+  const int hf = __builtin_amdgcn_readfirstlane((tid / Cfg::UW) % Cfg::HALVES);   // which half of the unit's channels
+  const int lu = tid % (Cfg::UW * Cfg::HALVES);                                   // lane within the slot
+  const int sl = tid / (Cfg::UW * Cfg::HALVES);   // token slot (wave-uniform)
   const int g = blockIdx.x % a.groups;
   const int range = blockIdx.x / a.groups;
   const int b = blockIdx.z;
@@ -283,9 +291,10 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
       __syncthreads();   // (also frees the region for the pipeline / the next pass)
     }
     };
-  float acc[CH];
+  constexpr int CHL = Cfg::CHL;
+  float acc[CHL];
 #pragma unroll
-  for (int i = 0; i < CH; i++) acc[i] = 0.f;
+  for (int i = 0; i < CHL; i++) acc[i] = 0.f;
 
   // per-lane constant pieces of the LDS addresses
   int rowoff[WORDS], rot[WORDS];
@@ -365,12 +374,15 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
           });
         } else {
           const float *tab = reinterpret_cast<const float *>(lutb) + ((qq * 4 + e) * Cfg::SLOTS + sl) * N;
-          static_for<0, CH>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            acc[i] = fmaf(tab[vcode<BITS, i, WORDS>(w)], pt, acc[i]);
+          static_for<0, Cfg::HALVES>([&](auto HF) {      // (wave-uniform branch: the code positions are compile-time)
+            if (hf == decltype(HF)::value)
+              static_for<0, CHL>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                acc[i] = fmaf(tab[vcode<BITS, decltype(HF)::value * CHL + i, WORDS>(w)], pt, acc[i]);
+              });
           });
         }
-        if constexpr (CH > 8 || (e & 1))
+        if constexpr (CHL > 8 || (e & 1))
           __builtin_amdgcn_sched_barrier(0);   // 16 look-ups (two 4-bit tokens / one 2-bit token) or one 3-bit token's 32 in
                                                // flight at a time (VGPR budget)
       });
@@ -385,20 +397,20 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
   __syncthreads();
   float *red = reinterpret_cast<float *>(smem);
 #pragma unroll
-  for (int i = 0; i < CH; i++) red[(i * Cfg::SLOTS + sl) * Cfg::UW + ul] = acc[i];
+  for (int i = 0; i < CHL; i++) red[(i * Cfg::SLOTS + sl) * (Cfg::UW * Cfg::HALVES) + lu] = acc[i];
   __syncthreads();
   if (sl == 0 && ul < n_units_valid) {
-    float *dst = a.partial + ((int64_t)range * a.q_len + b) * C + (int64_t)(u0 + ul) * CH;
-    float o[CH];
+    float *dst = a.partial + ((int64_t)range * a.q_len + b) * C + (int64_t)(u0 + ul) * CH + hf * CHL;
+    float o[CHL];
 #pragma unroll
-    for (int i = 0; i < CH; i++) {
-      float s = red[(i * Cfg::SLOTS) * Cfg::UW + ul];
+    for (int i = 0; i < CHL; i++) {
+      float s = red[(i * Cfg::SLOTS) * (Cfg::UW * Cfg::HALVES) + lu];
 #pragma unroll
-      for (int k = 1; k < Cfg::SLOTS; k++) s += red[(i * Cfg::SLOTS + k) * Cfg::UW + ul];
+      for (int k = 1; k < Cfg::SLOTS; k++) s += red[(i * Cfg::SLOTS + k) * (Cfg::UW * Cfg::HALVES) + lu];
       o[i] = s;
     }
 #pragma unroll
-    for (int i = 0; i < CH; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+    for (int i = 0; i < CHL; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
   }
   if (sparse) {
     __syncthreads();   // the slot reduction is done with the LDS
