@@ -79,6 +79,7 @@ class QuantK(nn.Module):
         self.first_few_fp16 = first_few_fp16
         self.norm = False
         self.lookup_table2 = None
+        self.lut_ends = None
         self._reset_csr(dev)
 
     @property
