@@ -38,7 +38,7 @@
 
 #include <cstdlib>
 #ifndef KVQ_V_DBG
-#define KVQ_V_DBG 0
+#define KVQ_V_DBG 0   // development ablations (-DKVQ_V_DBG=n): 1 skip the math, 2 skip the DMA, 4 DMA from an L2-resident source
 #endif
 
 namespace kvq {
@@ -91,7 +91,6 @@ struct MixArgs {
   int n_units;
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out)
-  int dbg;                 // development only (compile with -DKVQ_V_DBG=n): 1 skip math, 2 skip DMA, 4 DMA from L2
 };
 
 // Per-lane constants of the chunk DMA.  Every tile DMA instruction of a wave moves 64/QR consecutive
@@ -313,8 +312,8 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
     const int64_t c0 = t0 + (int64_t)ci * CT;
     dma_wait_all();                       // this wave's DMA pieces of chunk ci have landed
     __syncthreads();                      // ... and everybody else's; the other stage is free again
-    if (ci + 1 < n_chunks && !(a.dbg & 2))
-      issue_chunk<BITS>(a, dl, lds0 + (1 - stage) * Cfg::BUF_B, (a.dbg & 4) ? t0 : c0 + CT, row_base, n_rows_valid, h0, b);
+    if (ci + 1 < n_chunks && !(KVQ_V_DBG & 2))
+      issue_chunk<BITS>(a, dl, lds0 + (1 - stage) * Cfg::BUF_B, (KVQ_V_DBG & 4) ? t0 : c0 + CT, row_base, n_rows_valid, h0, b);
     const unsigned char *tile = smem + stage * Cfg::BUF_B;
     const unsigned char *lutb = smem + stage * Cfg::BUF_B + Cfg::TILE_B;
     float *pb = reinterpret_cast<float *>(smem + stage * Cfg::BUF_B + Cfg::TILE_B + Cfg::LUT_B);
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
         if (i % CT >= rem) pb[i] = 0.f;
       __syncthreads();
     }
-    if (a.dbg & 1) return;
+    if (KVQ_V_DBG & 1) return;
     int rotv[WORDS];
 #pragma unroll
     for (int wi = 0; wi < WORDS; wi++) {
@@ -575,7 +574,6 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
   a.n_units = 0;
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
-  a.dbg = KVQ_V_DBG;
   switch (bits) {
     case 4: return launch_mix<4>(a, mul, accumulate, st);
     case 3: return launch_mix<3>(a, mul, accumulate, st);

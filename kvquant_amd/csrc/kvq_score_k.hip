@@ -74,7 +74,6 @@ struct ScoreKArgs {
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out): e / n_out == umulhi(e, magic) for e < 2^32 / n_out
   int accumulate;
-  int dbg_tmask;
   // optional fusion of the first softmax pass (sparse variant, q_len = 1, accumulate = 0): per (head, tile)
   // max and sum of exp of the SCALED scores, [H][sm_nparts][2]
   float *sm_parts;
@@ -240,7 +239,7 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
   uint32_t wlo_all[PF][BITS], whi_all[PF][BITS];
   float oldv[PF];   // dense + accumulate: the score's previous value travels with the head's words
   // lane offset inside a head's rows: role r starts BITS rows further down (host checks it fits 32 bits)
-  const uint32_t woff = (uint32_t)(((int64_t)role * BITS * a.max_len + (tc & a.dbg_tmask)) * 4);
+  const uint32_t woff = (uint32_t)(((int64_t)role * BITS * a.max_len + (tc & KVQ_K_TMASK)) * 4);
   const bool acc_dense = !SPARSE && a.accumulate;
   const uint32_t toff = (uint32_t)tc * 4u;
   auto load_old = [&](float &dst, int hh) {
@@ -703,7 +702,6 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.accumulate = accumulate;
-  a.dbg_tmask = KVQ_K_TMASK;
   a.sm_parts = sm_parts;
   a.sm_inv = sm_inv;
   a.sm_nparts = sm_nparts;
