@@ -87,12 +87,13 @@ struct ScoreKArgs {
 // destination registers until the explicit vm_wait<0>() at the top of the next head (the two word sets
 // ping-pong, there is no register copy).
 template <int BITS>
-__device__ __forceinline__ void load_words(uint32_t (&w)[BITS], const uint32_t *__restrict__ mat,
-                                           int64_t row0, int64_t max_len, uint32_t voff) {
+__device__ __forceinline__ void load_words(uint32_t (&w)[BITS], const uint32_t *__restrict__ base,
+                                           int64_t max_len, uint32_t voff) {
 #pragma unroll
   for (int i = 0; i < BITS; i++) {
-    const uint32_t *base = mat + (row0 + i) * max_len;
     asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(w[i]) : "v"(voff), "s"(base) : "memory");
+    base += max_len;     // (one scalar 64-bit add per row instead of a 64-bit multiply: the kernel issues ~75
+                         //  SALU instructions per head iteration, most of them address arithmetic)
   }
 }
 
@@ -246,6 +247,9 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
     const float *base = a.mul + ((int64_t)b * a.H + h0 + hh) * a.L;
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(toff), "s"(base) : "memory");
   };
+  const uint32_t *mat_h0 = a.mat + (int64_t)h0 * WPH * a.max_len;   // first row of the group's first head
+  const int64_t head_words = (int64_t)WPH * a.max_len;               // words between consecutive heads
+  const int64_t hi_words = (int64_t)2 * BITS * a.max_len;            // ... between the lo and hi channel halves
   auto fetch_head = [&](int hh, auto SET) {   // everything head hh needs from memory -> set SET / table SET
     constexpr int set = decltype(SET)::value;
 #if KVQ_ABL & 4
@@ -253,8 +257,9 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
 #else
     issue_table(hh, set);
 #endif
-    load_words<BITS>(wlo_all[set], a.mat, (int64_t)(h0 + hh) * WPH, a.max_len, woff);
-    load_words<BITS>(whi_all[set], a.mat, (int64_t)(h0 + hh) * WPH + 2 * BITS, a.max_len, woff);
+    const uint32_t *hb = mat_h0 + (int64_t)hh * head_words;
+    load_words<BITS>(wlo_all[set], hb, a.max_len, woff);
+    load_words<BITS>(whi_all[set], hb + hi_words, a.max_len, woff);
     if (acc_dense) load_old(oldv[set], hh);
   };
   static_for<0, PF - 1>([&](auto U) {
