@@ -553,15 +553,20 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
         x[k] = (j < ntok && hh < nh) ? scaled(sc[j * SCS + ((hh + j) & (SCS - 1))], a.sm_inv) : -INFINITY;
         m = fmaxf(m, x[k]);
       }
+      // (hardware 2^x: these sums only feed the row normaliser Z, where a few ulp are far below the fp16
+      // rounding of the probabilities; the per-element exponentials of the second pass stay exact.  The
+      // accurate expf was ~5 % of the kernel: 24 calls per lane per tile.)
+      constexpr float kLog2e = 1.4426950408889634f;
+      auto ex = [&](float d) { return __builtin_amdgcn_exp2f(d * kLog2e); };   // d <= 0; 2^-inf = 0
       if (m > -INFINITY) {
 #pragma unroll
-        for (int k = 0; k < T / TPH; k++) sm += expf(x[k] - m);   // exp(-inf) = 0 for the padding
+        for (int k = 0; k < T / TPH; k++) sm += ex(x[k] - m);     // 0 for the padding
       }
 #pragma unroll
       for (int d = TPH / 2; d >= 1; d >>= 1) {
         const float mo = __shfl_xor(m, d), so = __shfl_xor(sm, d);
         const float mn = fmaxf(m, mo);
-        sm = (mn == -INFINITY) ? 0.f : sm * expf(m - mn) + so * expf(mo - mn);
+        sm = (mn == -INFINITY) ? 0.f : sm * ex(m - mn) + so * ex(mo - mn);
         m = mn;
       }
       if (r == 0 && hh < nh) {
