@@ -25,6 +25,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// 2^(d log2 e) with the hardware exponential, for the weights that merge partial sums into the row normaliser
+// (a few ulp there are far below the fp16 rounding of the probabilities; the per-element exponentials of the
+// normalising pass use expf)
+__device__ __forceinline__ float exp_w(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
+
 // block-wide (max, sum) merge of per-lane online-softmax state (NW waves, red[2 * NW])
 template <int NW = 4>
 __device__ __forceinline__ void block_merge(float &m, float &s, float *red) {
@@ -33,7 +38,7 @@ __device__ __forceinline__ void block_merge(float &m, float &s, float *red) {
   for (int d = 32; d >= 1; d >>= 1) {
     const float mo = __shfl_xor(m, d), so = __shfl_xor(s, d);
     const float mn = fmaxf(m, mo);
-    s = (mn == -INFINITY) ? 0.f : s * expf(m - mn) + so * expf(mo - mn);
+    s = (mn == -INFINITY) ? 0.f : s * exp_w(m - mn) + so * exp_w(mo - mn);
     m = mn;
   }
   const int w = threadIdx.x >> 6;
@@ -44,7 +49,7 @@ __device__ __forceinline__ void block_merge(float &m, float &s, float *red) {
   for (int i = 1; i < NW; i++) M = fmaxf(M, red[i]);
   float S = 0.f;
 #pragma unroll
-  for (int i = 0; i < NW; i++) if (red[i] > -INFINITY) S += red[NW + i] * expf(red[i] - M);
+  for (int i = 0; i < NW; i++) if (red[i] > -INFINITY) S += red[NW + i] * exp_w(red[i] - M);
   m = M;
   s = S;
 }
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restri
     const float2 ms = *reinterpret_cast<const float2 *>(ws + ((int64_t)h * n_parts + i) * 2);
     if (ms.x > -INFINITY) {
       const float mn = fmaxf(M, ms.x);
-      Z = Z * expf(M - mn) + ms.y * expf(ms.x - mn);   // (M = -inf: Z = 0)
+      Z = Z * exp_w(M - mn) + ms.y * exp_w(ms.x - mn);   // (M = -inf: Z = 0)
       M = mn;
     }
   }
