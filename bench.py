@@ -214,6 +214,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     from kvquant_amd import _lib
+    if os.environ.get("KVQ_LIB"):      # development: time an alternative build of the library (tools/abl)
+        _lib.LIB_PATH = os.path.abspath(os.environ["KVQ_LIB"])
     _lib.lib()  # fail loudly if the HIP library is missing
 
     total = args.steps + args.warmup

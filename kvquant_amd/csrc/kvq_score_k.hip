@@ -631,7 +631,10 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   if (a.hpg > max_hpg) return KVQ_EINVAL;
   a.full_blocks = (int)(full_tiles * a.groups);
   // ragged last tile: few heads per workgroup, so that it is a short tail rather than an extra round
-  a.hpg_tail = full_tiles ? (SPARSE ? 4 : 2) : a.H / pick_groups(a.H, 1, q_len, max_hpg, slots);
+#ifndef KVQ_HPG_TAIL
+#define KVQ_HPG_TAIL 1   // measured at 128K + 1 (mirror variant, in bench.py): 1 -> 86.4, 2 -> 87.2, 4 -> 88.6, 8 -> 93.2 us
+#endif
+  a.hpg_tail = full_tiles ? (SPARSE ? KVQ_HPG_TAIL : 2) : a.H / pick_groups(a.H, 1, q_len, max_hpg, slots);
   if (a.hpg_tail > a.H) a.hpg_tail = a.H;
   const int tail_blocks = rem ? (a.H + a.hpg_tail - 1) / a.hpg_tail : 0;
   dim3 grid((unsigned)(a.full_blocks + tail_blocks), 1, q_len), block(NWAVES * 64);
