@@ -52,6 +52,13 @@ KVQ_API const char *kvq_strerror(int code);
 /* last hipError_t seen by a failing call on this thread (0 = none) */
 KVQ_API int kvq_last_hip_error(void);
 
+/* The 64 RoPE frequencies theta_j = powf(rope_theta, -2j/128) exactly as the score
+ * kernels evaluate them -- on the device, like the reference (KCU:3081, 508, 584) --
+ * written to out[0..63] (device).  For callers and checkers that need the same
+ * values (the device powf differs from the correctly rounded one by 1 ulp for some j,
+ * which is 6e-8 * position radians in the angle). */
+KVQ_API int kvq_rope_freqs(float rope_theta, float *out, void *stream);
+
 /* ---- append one token -------------------------------------------------- */
 
 /* vecquant{2,3,4}appendvecK (KCPP:5-33; KCU:1167-1245, 1322-1425, 1528-1607):

@@ -17,6 +17,7 @@ SIGNATURES = {
     "kvq_version": (_i, []),
     "kvq_strerror": (ctypes.c_char_p, [_i]),
     "kvq_last_hip_error": (_i, []),
+    "kvq_rope_freqs": (_i, [_f, _vp, _vp]),
     "kvq_append_k": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "kvq_append_v": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "kvq_append_k_sparse": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),

@@ -1,7 +1,12 @@
 // Library-level entry points of libkvq.so (version, error strings).
+#include "kvq_common.h"
 #include "kvq_host.h"
 
 namespace kvq {
+__global__ void rope_freqs_kernel(float rope_theta, float *out) {
+  if (threadIdx.x < kHeadDim / 2) out[threadIdx.x] = rope_freq(rope_theta, threadIdx.x);
+}
+
 int &last_hip_error_ref() {
   static thread_local int e = 0;
   return e;
@@ -10,7 +15,7 @@ int &last_hip_error_ref() {
 
 extern "C" {
 
-int kvq_version(void) { return 100; }
+int kvq_version(void) { return 200; }
 
 const char *kvq_strerror(int code) {
   switch (code) {
@@ -23,5 +28,11 @@ const char *kvq_strerror(int code) {
 }
 
 int kvq_last_hip_error(void) { return kvq::last_hip_error_ref(); }
+
+int kvq_rope_freqs(float rope_theta, float *out, void *stream) {
+  if (!out || !(rope_theta > 0.f)) return KVQ_EINVAL;
+  kvq::rope_freqs_kernel<<<1, 64, 0, (hipStream_t)stream>>>(rope_theta, out);
+  return kvq::check_launch();
+}
 
 }  // extern "C"

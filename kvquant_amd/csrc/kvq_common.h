@@ -118,9 +118,14 @@ __device__ __forceinline__ void sincos_rev(float ang, float &s, float &c) {
   c = __builtin_amdgcn_cosf(r);
 }
 
-struct RopeFreqs {
-  float f[kHeadDim / 2];  // theta^(-2j/128), j = 0..63, computed on the host
-};
+// theta_j = powf(rope_theta, -2j/128), j = 0..63, evaluated ON THE DEVICE exactly as the reference writes it
+// (KCU:3081: powf(rope_theta, (-2 * __int2float_rd(off % headdim2) / __int2float_rd(headdim)))).  The device
+// powf is part of the contract: on MI355X it differs from the correctly rounded value by 1 ulp for 21 of the
+// 64 frequencies, and 1 ulp of theta_j is 6e-8 * pos radians -- 8e-3 rad at 128K, 6e-2 at 1M
+// (tests/test_ref_gpu.py measures both against the reference's own kernels built for this GPU).
+__device__ __forceinline__ float rope_freq(float rope_theta, int j) {
+  return powf(rope_theta, (-2 * (float)j / (float)kHeadDim));
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void spmv_k_rope_csr_kernel(const int32_t *__r
                                                               const float *__restrict__ vals,
                                                               const float *__restrict__ q, float *__restrict__ mul,
                                                               int64_t num_rows, int64_t L, int pos_offset,
-                                                              RopeFreqs fr) {
+                                                              float rope_theta) {
   __shared__ float theta[64];
-  if (threadIdx.x < 64) theta[threadIdx.x] = fr.f[threadIdx.x];
+  if (threadIdx.x < 64) theta[threadIdx.x] = rope_freq(rope_theta, threadIdx.x);   // KCU:584
   __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= num_rows || t >= L) return;
@@ -157,13 +157,6 @@ __global__ __launch_bounds__(1024) void spmv_v_csc_kernel(const int32_t *__restr
   }
 }
 
-static RopeFreqs freqs_of(float rope_theta) {
-  RopeFreqs fr;
-  for (int j = 0; j < kHeadDim / 2; j++)
-    fr.f[j] = (float)std::pow((double)rope_theta, (double)(-2.0f * (float)j / (float)kHeadDim));
-  return fr;
-}
-
 }  // namespace kvq
 
 using namespace kvq;
@@ -202,7 +195,7 @@ int kvq_spmv_k_rope_csr(const int32_t *rowptr, const int32_t *cols, const float 
   if (num_rows == 0 || L == 0) return KVQ_OK;
   if (!cols || !vals) return KVQ_EINVAL;
   spmv_k_rope_csr_kernel<<<(unsigned)((num_rows + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      rowptr, cols, vals, q, mul, num_rows, L, pos_offset, freqs_of(rope_theta));
+      rowptr, cols, vals, q, mul, num_rows, L, pos_offset, rope_theta);
   return check_launch();
 }
 

@@ -79,6 +79,7 @@ struct ScoreKArgs {
   float *sm_parts;
   float sm_inv;
   int sm_nparts;
+  float rope_theta;
 };
 
 // BITS consecutive word-rows starting at uniform row `row0`, each read at the lane's byte offset `voff`:
@@ -115,7 +116,7 @@ constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse varian
 // rows: a lane then owns ITS token's entries (coalesced loads, no segmented scan, no index division).
 template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false>
 __global__ __launch_bounds__(NWAVES * 64, 4) 
-void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
+void score_k_kernel(ScoreKArgs a) {
   static_assert(!TRANSPOSED || SPARSE, "the transposed mirror is a sparse variant");
   constexpr int N = Fmt<BITS>::kN;
   constexpr int WPH = Fmt<BITS>::kWordsPerHead;
@@ -229,7 +230,7 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
   int spc_all[2] = {0, 0};
 
   // RoPE frequency j lives in lane j of one VGPR (64 lanes = 64 frequencies); theta_of(j) is a wave shuffle
-  const float th_reg = fr.f[lane];
+  const float th_reg = rope_freq(a.rope_theta, lane);
   auto theta_of = [&](int j) { return __shfl(th_reg, j); };
   if constexpr (SPARSE) {
     for (int i = tid; i < T * SCS; i += NT) sc[i] = 0.f;
@@ -578,17 +579,6 @@ void score_k_kernel(ScoreKArgs a, RopeFreqs fr) {
   }
 }
 
-// theta_j = powf(rope_theta, -2j/128) (KCU:3083): correctly rounded from double
-// (the oracle uses the same definition).
-static RopeFreqs make_freqs(float rope_theta) {
-  RopeFreqs fr;
-  for (int j = 0; j < kHeadDim / 2; j++) {
-    float e = -2.0f * (float)j / (float)kHeadDim;
-    fr.f[j] = (float)std::pow((double)rope_theta, (double)e);
-  }
-  return fr;
-}
-
 static int workgroup_slots(int wg_per_cu) {
   static int cus = 0;
   if (cus == 0) {
@@ -639,7 +629,8 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   const int tail_blocks = rem ? (a.H + a.hpg_tail - 1) / a.hpg_tail : 0;
   dim3 grid((unsigned)(a.full_blocks + tail_blocks), 1, q_len), block(NWAVES * 64);
   if (a.sm_parts != nullptr && (!SPARSE || a.sm_nparts != (int)((a.L + T - 1) / T))) return KVQ_EINVAL;
-  score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED><<<grid, block, 0, st>>>(a, make_freqs(rope_theta));
+  a.rope_theta = rope_theta;
+  score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED><<<grid, block, 0, st>>>(a);
   return check_launch();
 }
 

@@ -73,6 +73,15 @@ def _L():
     return _lib.lib()
 
 
+def rope_freqs(theta, device=None):
+    """theta_j = powf(theta, -2j/128), j < 64, as the score kernels evaluate them (on the device)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.empty(64, dtype=torch.float32, device=dev)
+    with _Dev(out):
+        _lib.check(_L().kvq_rope_freqs(float(theta), out.data_ptr(), _stream()), "kvq_rope_freqs")
+    return out
+
+
 def append_k(bits, mat, lut, x, col):
     H, hd, max_len = _cache_dims(mat, bits)
     with _Dev(mat):

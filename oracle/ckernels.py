@@ -111,6 +111,16 @@ def unpack_codes(bits, mat, C, L):
     return codes
 
 
+def set_rope_freqs(theta, table=None):
+    """install the platform's theta_j table (float32 [hd/2], CPU) for `theta`, or clear it (None): see the
+    comment at kvqo_rope_freq"""
+    if table is None:
+        lib().kvqo_set_rope_freqs(_cf(0.0), None, 0)
+        return
+    t = table.detach().cpu().float().contiguous()
+    lib().kvqo_set_rope_freqs(_cf(theta), _f(t), t.numel())
+
+
 def rope_freq(theta, k, hd):
     return lib().kvqo_rope_freq(_cf(theta), k, hd)
 

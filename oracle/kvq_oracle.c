@@ -5,13 +5,18 @@
  * call this file.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg use it, and only as the checker.
  *
- * Parity status: the reference ships no golden vectors / KATs for this path
- * and its kernels are CUDA (not runnable here), so the kernel arithmetic
- * below is "parity unpinned" against a running reference.  It is a scalar,
- * sequential restatement of the cited reference lines.  The host glue around
- * it (oracle/glue.py) IS pinned: tests/golden/ holds outputs of the
- * reference's own QuantK/QuantV Python classes run in this container with
- * this file standing in for the CUDA extension (tests/golden/gen_golden.py).
+ * Parity status: PINNED to the running reference.  The reference ships no
+ * golden vectors / KATs for this path, but its own extension
+ * (quant_cuda.cpp + quant_cuda_kernel.cu) is built for gfx950 from the sources
+ * where they lie by oracle/build_ref.py -> oracle/_ref/ (git-ignored), and
+ * tests/test_ref_gpu.py runs all 34 of its ops on the MI355X next to this
+ * file and next to the HIP kernels: packed codes, rescaled values and CSR/CSC
+ * bookkeeping bit for bit, q.K^T / p.V within the 1e-3 tolerance (measured
+ * ~1e-6 .. 3e-4; the reference sums with atomics and is not bit-reproducible
+ * against itself).  Known reference defects that show up there are listed in
+ * that file's header.  The host glue around the kernels (oracle/glue.py) is
+ * pinned separately: tests/golden/ holds outputs of the reference's own
+ * QuantK/QuantV Python classes (tests/golden/gen_golden.py).
  *
  * Short names:
  *   KCU = /root/reference/deployment/kvquant/quant_cuda_kernel.cu
@@ -229,12 +234,35 @@ KVQO_EXPORT void kvqo_unpack_codes(int bits, const int32_t *mat, uint8_t *codes,
 /* K score: q.K^T with RoPE applied to the dequantised pre-RoPE key      */
 /* ------------------------------------------------------------------ */
 
-/* theta_k = powf(rope_theta, -2*(k % (hd/2))/hd) (KCU:3083).  The CUDA powf
- * is not available; this uses the correctly rounded value (double pow
- * rounded to float).  The exponent is exact in fp32 for hd a power of 2. */
+/* theta_k = powf(rope_theta, -2*(k % (hd/2))/hd) (KCU:3081, 508, 584).  The
+ * reference evaluates this with the DEVICE's powf; 1 ulp of theta_k moves the
+ * angle by 6e-8 * position radians, so at long contexts the platform's powf is
+ * part of the result (measured against the reference's own kernels on MI355X,
+ * tests/test_ref_gpu.py: the device powf differs from the correctly rounded
+ * value by 1 ulp for 21 of the 64 frequencies of theta = 10000, which is up to
+ * 2e-2 relative in a score at position 1e6).  Default here: the host libm's
+ * powf.  A checker that compares with a GPU run installs the device's table
+ * with kvqo_set_rope_freqs (obtained through kvq_rope_freqs of include/kvq.h or
+ * from the reference extension itself). */
+static float g_freq_tab[256];
+static float g_freq_theta = 0.f;
+static int g_freq_n = 0;
+
+KVQO_EXPORT void kvqo_set_rope_freqs(float rope_theta, const float *f, int n) {
+  if (!f || n <= 0 || n > 256) {
+    g_freq_n = 0;
+    return;
+  }
+  for (int i = 0; i < n; i++) g_freq_tab[i] = f[i];
+  g_freq_theta = rope_theta;
+  g_freq_n = n;
+}
+
 KVQO_EXPORT float kvqo_rope_freq(float rope_theta, int k, int hd) {
-  float e = -2.0f * (float)(k % (hd / 2)) / (float)hd;
-  return (float)pow((double)rope_theta, (double)e);
+  int j = k % (hd / 2);
+  if (g_freq_n == hd / 2 && g_freq_theta == rope_theta) return g_freq_tab[j];
+  float e = -2.0f * (float)j / (float)hd;
+  return powf(rope_theta, e);
 }
 
 /* vecquant{b}matmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt

@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.kvq_version() >= 100
+    assert lib.kvq_version() >= 200
     assert b"invalid" in lib.kvq_strerror(-1)
     # argument validation happens before any launch, so these are safe without a GPU
     assert lib.kvq_append_k(5, None, None, None, 32, 128, 16, 0, None) == -1
@@ -51,10 +51,7 @@ def test_legacy_module_surface():
     from oracle import quant_cuda_ref
     ours = {n for n in dir(quant_cuda) if n.startswith("vecquant")}
     ref = set(quant_cuda_ref.NAMES)
-    # the four uncapped-CSR ("_orig") entry points are the only ones not built yet
-    missing = ref - ours
-    assert all("orig" in n for n in missing), missing
-    assert len(ours) >= 30
+    assert ours == ref and len(ours) == 34
 
 
 def test_shim_rejects_cpu_tensors():
@@ -72,3 +69,7 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "quant_cuda_ref" not in txt and "build_ref" not in txt and "oracle/_ref" not in txt, f
+    # bench.py may use the oracle only inside cpu_baseline(); the reference build never
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    assert "build_ref" not in b and "quant_cuda_ref" not in b

@@ -159,7 +159,11 @@ def test_score_softmax_fused_matches_two_pass(gpu, bits, L, n_sink):
     s3 = torch.zeros(1, H, L, device=gpu)
     p3, sp3 = ops.score_k_softmax(bits, mg, s3, lg, L, 10000.0, 0, ws, vg, ig, inv, sink, vt, it)
     assert util.rel_err(s3.cpu().reshape(1, -1), ref.reshape(1, -1)) < 2e-5
-    d = (p3 - p2).abs()
-    assert bool((d <= p2.abs() * 2e-3 + 1e-7).all()), float(d.max())
+    # its raw scores are summed in another order than s2 (equal to ~1e-6), and one fp16 ulp of a scaled score
+    # is up to 1.6 % of its probability (the reference's own half() pipeline, ML:873-874): the probabilities are
+    # therefore compared with the two-pass softmax of THIS variant's scores
+    p4, sp4 = ops.softmax_scale(s3[0], inv, sink)
+    d = (p3 - p4).abs()
+    assert bool((d <= p4.abs() * 2e-3 + 1e-7).all()), float(d.max())
     if n_sink:
-        assert bool(((sp3.float() - sp2.float()).abs() <= sp2.float().abs() * 2e-3 + 1e-7).all())
+        assert bool(((sp3.float() - sp4.float()).abs() <= sp4.float().abs() * 2e-3 + 1e-7).all())

@@ -61,3 +61,12 @@ def rel_err(a, b, dim=-1):
     b = b.double()
     scale = b.abs().amax(dim=dim, keepdim=True).clamp_min(1e-12)
     return float(((a - b).abs() / scale).max())
+
+
+def sync_oracle_freqs(theta=10000.0):
+    """Give the CPU oracle the RoPE frequency table of THIS GPU (theta_j = powf on the device, as the
+    reference evaluates it): call at the top of GPU tests that compare scores at long positions."""
+    import torch as _t
+    from kvquant_amd import ops
+    from oracle import ckernels
+    ckernels.set_rope_freqs(theta, ops.rope_freqs(theta).cpu())
