@@ -12,6 +12,14 @@ _i64 = ctypes.c_int64
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
 
+class VNorm(ctypes.Structure):
+    """struct kvq_vnorm of include/kvq.h"""
+    _fields_ = [("lut_rows2", ctypes.c_void_p), ("normscale", ctypes.c_float), ("normoffset", ctypes.c_float),
+                ("zp_from_rows2", ctypes.c_int)]
+
+
+_vn = ctypes.POINTER(VNorm)
+
 # name -> (restype, argtypes); mirrors include/kvq.h one to one
 SIGNATURES = {
     "kvq_version": (_i, []),
@@ -29,13 +37,13 @@ SIGNATURES = {
     "kvq_mix_v_workspace_bytes": (_sz, [_i, _i, _i, _i, _i64]),
     "kvq_mix_v": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_append_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _vp]),
-    "kvq_append_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "kvq_append_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vn, _vp]),
     "kvq_pack_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "kvq_pack_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
+    "kvq_pack_v_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vn, _vp]),
     "kvq_softmax_workspace_bytes": (_sz, [_i, _i64]),
     "kvq_softmax_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp, _sz, _vp]),
     "kvq_decode_prologue": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                 _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                 _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vn, _vp, _sz, _vp]),
     "kvq_score_k_prepared": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_score_k_softmax_parts": (_i, [_i, _i64, _i]),
     "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,

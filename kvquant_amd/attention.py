@@ -137,7 +137,7 @@ class KVQuantAttention(nn.Module):
         sink_scores = None
         if sinks > 0:
             sink_scores = (torch.matmul(query_rope, self.kcache_fp16) / math.sqrt(hd))[0, :, 0, :].contiguous()
-        if self.kcache.include_sparse and self.vcache.include_sparse and not self.vcache.norm:
+        if self.kcache.include_sparse and self.vcache.include_sparse:
             out, sink_probs = decode_kv(self.kcache, self.vcache, query_rope[0, :, 0, :].contiguous(),
                                         key_states.flatten(), value_states.flatten(), sink_scores)
             out = out.transpose(0, 1).half()                                   # [H, 1, hd]

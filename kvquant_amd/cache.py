@@ -29,6 +29,17 @@ def _threshold_k(sparsity_threshold, hidden_size):
     return int(((1 - sparsity_threshold) / 2) * hidden_size) + 1  # ML:706
 
 
+def _pack_col0(length, sinks):
+    """First compressed column of a parallel_pack.  The reference packs on an empty cache (columns 0..S-1) and
+    counts its fp16 sink tokens AFTERWARDS (ML:1877-1888); chunked fills call it again with the sinks already in
+    `length`.  Either way the next compressed column is the number of compressed tokens so far."""
+    if length == 0:
+        return 0
+    if length < sinks:
+        raise ValueError("parallel_pack while the fp16 sink cache is still filling (len %d < %d)" % (length, sinks))
+    return length - sinks
+
+
 def _default_device(device):
     if device is not None:
         return torch.device(device)
@@ -201,14 +212,14 @@ class QuantK(nn.Module):
             raise AssertionError("parallel_pack needs include_sparse (as the reference, ML:975)")
         k = k.float().contiguous()
         S = k.shape[-1]
-        col0 = self.klen
-        self.klen += S
+        col0 = _pack_col0(self.klen, self.first_few_fp16)
         if fused:
             # one launch: pack + exact top-k selection + outlier rows (+ mirror), one workgroup per token
             lut_off = self.lookup_table2 if self.norm else self.lookup_table
             ops.pack_k_fused(self.bits, self.kcache, self.lookup_table, lut_off, k, self.outlier_threshold_lower,
                              self.outlier_threshold_upper, self.outliers, self.outlier_indices,
                              self.num_outliers // 2, col0, self.outliers_t, self.outlier_indices_t)
+            self.klen += S        # (only once the library call has succeeded)
             return
         resc = torch.empty_like(k)
         ops.pack_k_sparse_parallel(self.bits, self.kcache, self.lookup_table, k, resc,
@@ -220,7 +231,7 @@ class QuantK(nn.Module):
         self.outlier_indices[col0:col0 + S] = idx
         self.outliers_t[:, col0:col0 + S] = vals.t()
         self.outlier_indices_t[:, col0:col0 + S] = idx.t()
-
+        self.klen += S
 
     # ---- uncapped outliers (use_orig_sparse=True), 4 bit only ---------------------------------------
     def forward_fused_sparse_orig(self, q, k):
@@ -251,10 +262,10 @@ class QuantK(nn.Module):
         assert self.include_sparse and self.bits == 4
         k = k.float().contiguous()
         S = k.shape[-1]
-        self.klen += S
         resc = torch.empty_like(k)
         ops.pack_k_sparse_parallel(4, self.kcache, self.lookup_table, k, resc, self.outlier_threshold_lower,
                                    self.outlier_threshold_upper, 0)
+        self.klen += S
         k = k.reshape(-1, S).clone()
         lower = k < self.outlier_threshold_lower.unsqueeze(-1)
         above = k > self.outlier_threshold_upper.unsqueeze(-1)
@@ -335,6 +346,9 @@ class QuantV(nn.Module):
         if norm:
             self.normscale = torch.as_tensor(quantizer[3]).to(self.device)
             self.normoffset = torch.as_tensor(quantizer[4]).to(self.device)
+            # the same two numbers as fp32 host scalars for the fused kernels (one sync, at load time only)
+            self._ns = float(self.normscale.float())
+            self._no = float(self.normoffset.float())
             self.lookup_table2 = torch.zeros((self.max_len, 2 ** self.bits), dtype=torch.float32,
                                              device=self.device)
         else:
@@ -350,17 +364,29 @@ class QuantV(nn.Module):
         lv, li = torch.topk(v_tok_major, k, dim=-1, largest=False)
         return uv, ui, lv, li
 
+    def vnorm_args(self, prefill=False):
+        """Q-Norm argument of the fused V appends: second per-token row table + (scale, offset) + which table the
+        sparse residuals refer to -- the Q-Norm row at 2 bit in decode (ML:1153-1156) and at every width in the
+        prefill glue (ML:1369-1375).  None without Q-Norm."""
+        if not self.norm:
+            return None
+        return (self.lookup_table2, self._ns, self._no, prefill or self.bits == 2)
+
+    def mix_table(self):
+        """table the p.V kernel dequantises with: the Q-Norm rows at 2 bit (ML:1237-1240)"""
+        return self.lookup_table2 if (self.norm and self.bits == 2) else self.lookup_table
+
     def append_and_mix(self, p, v):
         """The GPU-resident core of forward_fused_sparse: p f32 [q_len, H, L+1] probabilities,
-        v f32 [C].  Appends v (thresholds, codebook row, pack, outlier row: one launch) and returns
+        v f32 [C].  Appends v (thresholds, codebook row(s), pack, outlier row: one launch) and returns
         f32 [q_len, H, hd] (two launches).  No host synchronisation.  include_sparse only."""
         pos = self.vlen - self.first_few_fp16
         ops.append_v_fused(self.bits, self.vcache, self.lookup_table, self.lut, v, self.outliers,
-                           self.outlier_indices, self.num_outliers // 2, pos)
+                           self.outlier_indices, self.num_outliers // 2, pos, self.vnorm_args())
         self.vlen += 1
         L = self.vlen - self.first_few_fp16
         mul = torch.empty((p.shape[0], p.shape[1], self.head_dim), dtype=torch.float32, device=p.device)
-        ops.mix_v(self.bits, p, self.vcache, mul, self.lookup_table, L, self.outliers, self.outlier_indices,
+        ops.mix_v(self.bits, p, self.vcache, mul, self.mix_table(), L, self.outliers, self.outlier_indices,
                   accumulate=False)
         return mul
 
@@ -373,7 +399,7 @@ class QuantV(nn.Module):
         score = score.float()
         v_in = v.flatten()
         v = v_in.float().contiguous()
-        if self.include_sparse and upper_outlier_vals is None and not self.norm:
+        if self.include_sparse and upper_outlier_vals is None:
             mul = self.append_and_mix(score.transpose(0, 1).contiguous(), v)
             return mul.transpose(0, 1).contiguous().half()
         pos = self.vlen - self.first_few_fp16
@@ -397,7 +423,8 @@ class QuantV(nn.Module):
             maxval, minval = v_in.max(), v_in.min()
             offset = (maxval + minval) / 2
             sf = (maxval - minval) / 2
-        # ML:1113: lut * sf.item() + offset.item() in fp32, kept on the GPU (no .item() sync)
+        # ML:1113: lut * sf.item() + offset.item() in fp32; sf / offset / thresholds stay on the GPU as 0-d
+        # tensors (the reference synchronises on .item() here)
         row = self.lut.float() * sf.float() + offset.float()
         self.lookup_table[pos] = row
         if self.norm:
@@ -406,7 +433,10 @@ class QuantV(nn.Module):
         if self.include_sparse:
             zp_row = self.lookup_table2[pos] if (self.norm and self.bits == 2) else row   # ML:1153-1156
             zeropoint = zp_row[zc]
-            ops.append_v_sparse(self.bits, self.vcache, self.lookup_table, v, float(minval), float(maxval), pos)
+            # vecquant{b}appendvecVsparse with the two thresholds read from device memory: the one-token case of the
+            # parallel pack entry point (per-token threshold arrays), so nothing is copied to the host
+            ops.pack_v_sparse_parallel(self.bits, self.vcache, self.lookup_table, v.view(self.num_heads, self.head_dim, 1),
+                                       minval.float().reshape(1), maxval.float().reshape(1), pos)
             vals = torch.cat((uv, lv), dim=-1) - zeropoint
             idx = torch.cat((ui, li), dim=-1)
             idx, order = idx.sort()
@@ -434,12 +464,12 @@ class QuantV(nn.Module):
             raise AssertionError("parallel_pack needs include_sparse (as the reference, ML:1322)")
         v = v.float().contiguous()
         S = v.shape[-1]
-        col0 = self.vlen
-        self.vlen += S
-        if upper_outlier_vals is None and not self.norm:
+        col0 = _pack_col0(self.vlen, self.first_few_fp16)
+        if upper_outlier_vals is None:
             # one launch: top-(k+1) selection, per-token codebook rows, pack, outlier rows
             ops.pack_v_fused(self.bits, self.vcache, self.lookup_table, self.lut, v, self.outliers,
-                             self.outlier_indices, self.num_outliers // 2, col0)
+                             self.outlier_indices, self.num_outliers // 2, col0, self.vnorm_args(prefill=True))
+            self.vlen += S
             return
         if upper_outlier_vals is None:
             vt = v.reshape(-1, S).t().contiguous()
@@ -453,6 +483,12 @@ class QuantV(nn.Module):
         sf = (maxval - minval) / 2
         rows = self.lut.float().unsqueeze(0) * sf.unsqueeze(-1) + offset.unsqueeze(-1)
         self.lookup_table[col0:col0 + S] = rows
+        if self.norm:
+            # (the reference's prefill glue reads lookup_table2[:, zero code] for the residuals, ML:1369-1375, but
+            # never fills those rows -- they are still zero from the constructor; the rows are written here, which
+            # is what its decode path does for every later token, ML:1116-1118)
+            self.lookup_table2[col0:col0 + S] = (self.lut.float() * self.normscale + self.normoffset).unsqueeze(0) \
+                * sf.unsqueeze(-1) + offset.unsqueeze(-1)
         ops.pack_v_sparse_parallel(self.bits, self.vcache, self.lookup_table, v, minval, maxval, col0)
         zc = ZERO_CODE[self.bits]
         zp_src = self.lookup_table2 if self.norm else self.lookup_table
@@ -462,6 +498,7 @@ class QuantV(nn.Module):
         vals = torch.gather(vals, 1, order)
         self.outliers[col0:col0 + S] = vals
         self.outlier_indices[col0:col0 + S] = idx.int()
+        self.vlen += S
 
 
 def decode_kv(kc, vc, q, k, v, sink_scores=None):
@@ -471,26 +508,28 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     q: [H, hd] RoPE'd query, k, v: [C] pre-RoPE key / value, all fp16 or all fp32 (no conversion
     launches).  sink_scores: optional f16 [H, n_sink] already scaled scores of the fp16 sink tokens.
     Returns (out f32 [1, H, hd], sink_probs f16 [H, n_sink] or None).  Sparse (include_sparse) caches only."""
-    if not (kc.include_sparse and vc.include_sparse) or vc.norm:
-        raise ValueError("decode_kv needs include_sparse caches without V Q-Norm")
+    if not (kc.include_sparse and vc.include_sparse):
+        raise ValueError("decode_kv needs include_sparse caches")
     bits = kc.bits
     kpos = kc.klen - kc.first_few_fp16
     vpos = vc.vlen - vc.first_few_fp16
     lut_off = kc.lookup_table2 if kc.norm else kc.lookup_table
+    # the score tables are built from the table the reference dequantises with: the Q-Norm one at 2 bit (ML:811-815)
+    table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
     ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
                              kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
                              vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
-                             kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t, kc.lut_ends)
+                             kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t, kc.lut_ends,
+                             None if table is kc.lookup_table else table, vc.vnorm_args())
     kc.klen += 1
     vc.vlen += 1
     L = kc.klen - kc.first_few_fp16
     H = kc.num_heads
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
-    table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
     probs, sink_probs = ops.score_k_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
                                             kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), sink_scores,
                                             kc.outliers_t, kc.outlier_indices_t)
     out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
-    ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.lookup_table, L, vc.outliers, vc.outlier_indices,
+    ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
               accumulate=False)
     return out, sink_probs

@@ -136,6 +136,9 @@ struct AppendArgs {
   const float *lut_off;    // K: table the residuals refer to (lut, or the Q-Norm table)
   float *lut_rows;         // V: [max_len][N], row `col` is written
   const float *lut_sorted; // V: [N]
+  float *lut_rows2;        // V Q-Norm (optional): [max_len][N], row `col` = (lut_sorted*normscale+normoffset)*sf+off
+  float normscale, normoffset;
+  int zp_from_rows2;       // V Q-Norm: the residuals refer to lut_rows2[col][zero code] (ML:1153-1156, 1369-1375)
   const void *x;           // element of channel c: x[c * x_stride] (fp32 or fp16); decode: [C], stride 1
   int x_is_half;
   int64_t x_stride;        // prefill pack: channel-major [C][S] input, stride S, x points at the token's column
@@ -171,7 +174,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   constexpr int N = Fmt<BITS>::kN;
   constexpr int E = kMaxPerLane;
   __shared__ SelShared sh;
-  __shared__ float vrow[16];
+  __shared__ float vrow[16], vrow2[16];
   const int tid = threadIdx.x;
   const int per = (C + kSelThreads - 1) / kSelThreads;   // channels per lane (4 at C = 4096), <= E
   const int c0 = tid * per;
@@ -278,9 +281,14 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
       const float r = lut_sorted[tid] * sf + offset;   // two roundings (-ffp-contract=off), ML:1113
       vrow[tid] = r;
       lut_rows[col * N + tid] = r;
+      if (A.lut_rows2 != nullptr) {                    // Q-Norm row, ML:1116-1118 (fp32, one rounding per op)
+        const float r2 = (lut_sorted[tid] * A.normscale + A.normoffset) * sf + offset;
+        vrow2[tid] = r2;
+        A.lut_rows2[col * N + tid] = r2;
+      }
     }
     __syncthreads();
-    zp = vrow[Fmt<BITS>::kZeroCode];
+    zp = (A.lut_rows2 != nullptr && A.zp_from_rows2) ? vrow2[Fmt<BITS>::kZeroCode] : vrow[Fmt<BITS>::kZeroCode];
   }
 
   // ---- V codes (need the clip thresholds and the row built above) ----------------------------------------
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(kSelThreads) void fused_pack_kernel(AppendArgs A) {
 // are independent; run back to back they cost 27 + 16 + 4 us of mostly latency.
 struct PrologueArgs {
   AppendArgs k, v;
-  const float *klut;       // [H][128][N] (table source; == k.lut)
+  const float *klut;       // [H][128][N]: source of the score tables (k.lut, or the Q-Norm table at 2 bit)
   const void *q;           // [H][128] fp32 or fp16
   int q_is_half;
   unsigned char *tab;      // score workspace: tables, then q as fp32
@@ -455,6 +463,10 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
   a.lut_off = lut_off;
   a.lut_rows = nullptr;
   a.lut_sorted = nullptr;
+  a.lut_rows2 = nullptr;
+  a.normscale = 1.f;
+  a.normoffset = 0.f;
+  a.zp_from_rows2 = 0;
   a.x = x;
   a.x_is_half = x_is_half;
   a.lo = lo;
@@ -469,11 +481,18 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
 }
 
 static AppendArgs v_args(int32_t *mat, float *lut_rows, const float *lut_sorted, const void *x, int x_is_half,
-                         float *outliers, int32_t *idx, int thr_k, int H, int hd, int64_t max_len, int64_t col) {
+                         float *outliers, int32_t *idx, int thr_k, int H, int hd, int64_t max_len, int64_t col,
+                         const kvq_vnorm *norm) {
   AppendArgs a = k_args(mat, nullptr, nullptr, x, x_is_half, nullptr, nullptr, outliers, idx, thr_k, H, hd, max_len,
                         col);
   a.lut_rows = lut_rows;
   a.lut_sorted = lut_sorted;
+  if (norm != nullptr && norm->lut_rows2 != nullptr) {
+    a.lut_rows2 = norm->lut_rows2;
+    a.normscale = norm->normscale;
+    a.normoffset = norm->normoffset;
+    a.zp_from_rows2 = norm->zp_from_rows2;
+  }
   return a;
 }
 
@@ -493,9 +512,9 @@ int kvq_append_k_fused(int bits, int32_t *mat, const float *lut, const float *lu
 
 int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
                        float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
-                       int64_t col, void *stream) {
+                       int64_t col, const kvq_vnorm *norm, void *stream) {
   return launch_fused<true>(bits, v_args(mat, lut_rows, lut_sorted, x, 0, outliers, outlier_idx, thr_k, H, hd,
-                                         max_len, col), H, hd, (hipStream_t)stream);
+                                         max_len, col, norm), H, hd, (hipStream_t)stream);
 }
 
 static int launch_pack(bool is_v, int bits, AppendArgs a, int H, int hd, int64_t S, hipStream_t st) {
@@ -532,9 +551,9 @@ int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_
 
 int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
                      float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
-                     int64_t col0, int64_t S, void *stream) {
+                     int64_t col0, int64_t S, const kvq_vnorm *norm, void *stream) {
   return launch_pack(true, bits, v_args(mat, lut_rows, lut_sorted, x, 0, outliers, outlier_idx, thr_k, H, hd,
-                                        max_len, col0), H, hd, S, (hipStream_t)stream);
+                                        max_len, col0, norm), H, hd, S, (hipStream_t)stream);
 }
 
 int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klut_off, const void *k,
@@ -542,8 +561,8 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
                         int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
                         float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
                         int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
-                        const float *klut_ends, void *score_workspace, size_t score_workspace_bytes,
-                        void *stream) {
+                        const float *klut_ends, const float *klut_score, const kvq_vnorm *vnorm,
+                        void *score_workspace, size_t score_workspace_bytes, void *stream) {
   if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
   if (score_workspace_bytes < kvq_score_k_workspace_bytes(bits, 1, H) ||
       reinterpret_cast<uintptr_t>(score_workspace) % 16)
@@ -553,12 +572,13 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
                koutliers_t, kidx_t);
   P.k.codes_elsewhere = 1;   // (hd == 128 here: one table workgroup per head covers every channel)
   P.k.lut_ends = klut_ends;
-  P.v = v_args(vmat, vlut_rows, vlut_sorted, v, acts_are_half, voutliers, vidx, thr_k, H, hd, max_len, vcol);
+  P.v = v_args(vmat, vlut_rows, vlut_sorted, v, acts_are_half, voutliers, vidx, thr_k, H, hd, max_len, vcol,
+               vnorm);
   int rc = check_append(false, P.k, H, hd);
   if (rc) return rc;
   rc = check_append(true, P.v, H, hd);
   if (rc) return rc;
-  P.klut = klut;
+  P.klut = klut_score ? klut_score : klut;   // table the score images are built from (Q-Norm 2 bit: ML:811-815)
   P.q = q;
   P.q_is_half = acts_are_half;
   P.tab = reinterpret_cast<unsigned char *>(score_workspace);

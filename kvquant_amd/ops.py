@@ -1,11 +1,13 @@
 """Typed wrappers over the C ABI of libkvq.so (include/kvq.h): torch tensors in,
 raw device pointers + torch's current stream out.  Argument checks raise
 ValueError; a failing library call raises KvqError.  No CPU path."""
+import ctypes
+
 import torch
 
 from . import _lib
 
-_ws = {}  # device index -> workspace tensor for the V matvec partial sums
+_ws = {}  # (slot, device index, stream) -> workspace tensor
 
 
 def _stream():
@@ -42,7 +44,13 @@ def _cache_dims(mat, bits):
 
 
 def _workspace(device, nbytes, slot="mix"):
-    key = (slot, device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch buffers of the library calls (score tables + fp32 query, softmax partials, p.V slabs), one per
+    (slot, device, STREAM): calls on one stream are ordered, so consecutive layers can share them; work on another
+    stream of the same device (the reference runs a side stream, ML:1804-1820) gets its own and cannot clobber
+    tables or partials that are still being read.  A buffer that has to grow is replaced on its own stream,
+    where the caching allocator orders the reuse of the old one."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (slot, idx, torch.cuda.current_stream(idx).cuda_stream)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -194,7 +202,15 @@ def append_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices
                    "kvq_append_k_fused")
 
 
-def append_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col):
+def _vnorm(norm):
+    """norm: None or (lut_rows2 f32 [max_len, 2^bits], normscale, normoffset, zp_from_rows2) -> kvq_vnorm* / None"""
+    if norm is None:
+        return None
+    rows2, ns, no, zp2 = norm
+    return ctypes.byref(_lib.VNorm(_f(rows2, "lookup_table2"), float(ns), float(no), 1 if zp2 else 0))
+
+
+def append_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col, norm=None):
     """top-(thr_k+1) thresholds + codebook row + pack + outlier row, one launch."""
     H, hd, max_len = _cache_dims(mat, bits)
     if outliers.shape[1] != 2 * thr_k or outlier_indices.shape[1] != 2 * thr_k:
@@ -205,7 +221,7 @@ def append_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices
         _lib.check(_L().kvq_append_v_fused(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"),
                                            _f(lut_sorted, "lut"), _f(x, "newvec"), _f(outliers, "outliers"),
                                            _i(outlier_indices, "outlier_indices"), int(thr_k), H, hd, max_len,
-                                           int(col), _stream()), "kvq_append_v_fused")
+                                           int(col), _vnorm(norm), _stream()), "kvq_append_v_fused")
 
 
 def pack_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, thr_k, col0, outliers_t=None,
@@ -224,7 +240,7 @@ def pack_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, 
                    "kvq_pack_k_fused")
 
 
-def pack_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col0):
+def pack_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col0, norm=None):
     """prefill: x f32 [H, hd, S] -> cache columns, per-token codebook rows and outlier rows, one launch."""
     H, hd, max_len = _cache_dims(mat, bits)
     S = x.shape[-1]
@@ -234,7 +250,7 @@ def pack_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, 
         _lib.check(_L().kvq_pack_v_fused(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"), _f(lut_sorted, "lut"),
                                          _f(x, "newvec"), _f(outliers, "outliers"),
                                          _i(outlier_indices, "outlier_indices"), int(thr_k), H, hd, max_len,
-                                         int(col0), int(S), _stream()), "kvq_pack_v_fused")
+                                         int(col0), int(S), _vnorm(norm), _stream()), "kvq_pack_v_fused")
 
 
 def softmax_scale(scores, inv_sqrt_hd, sink_scores=None):
@@ -339,9 +355,11 @@ def _act(t, name):
 
 
 def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vmat, vlut_rows, vlut_sorted, v,
-                    voutl, vidx, vcol, q, thr_k, koutl_t=None, kidx_t=None, klut_ends=None):
+                    voutl, vidx, vcol, q, thr_k, koutl_t=None, kidx_t=None, klut_ends=None, klut_score=None,
+                    vnorm=None):
     """K fused append + V fused append + K codebook images for score_k_prepared in ONE launch.
-    q [H,128] (RoPE'd), k, v [C]: all fp32 or all fp16.  Returns the score workspace tensor."""
+    q [H,128] (RoPE'd), k, v [C]: all fp32 or all fp16.  klut_score: table the score images are built from
+    (default klut).  Returns the score workspace tensor."""
     H, hd, max_len = _cache_dims(kmat, bits)
     kp, kh = _act(k, "k")
     vp, vh = _act(v, "v")
@@ -357,6 +375,7 @@ def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vm
             _f(vlut_rows, "lookup_table"), _f(vlut_sorted, "lut"), vp, _f(voutl, "outliers"),
             _i(vidx, "outlier_indices"), int(vcol), qp, kh, int(thr_k), H, hd, max_len,
             *_mirror(koutl_t, kidx_t, thr_k, max_len), None if klut_ends is None else _f(klut_ends, "lut_ends"),
+            None if klut_score is None else _f(klut_score, "lut_score"), _vnorm(vnorm),
             ws.data_ptr(), ws.numel(), _stream()), "kvq_decode_prologue")
     return ws
 

@@ -20,12 +20,14 @@ def quantizer(bits, seed=0):
     return (upper, lower, [cent]), scale, shift
 
 
-def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=2e-3):
+def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=2e-3, norm=False):
     """prefill `prefill` tokens with parallel_pack, then `steps` decode tokens through decode_kv; returns the
     worst relative error of the attention outputs (asserts the packed state bit for bit)."""
     from kvquant_amd.cache import QuantK, QuantV, decode_kv
     from oracle.glue import OracleQuantK, OracleQuantV
     quant, scale, shift = quantizer(bits, seed=bits)
+    if norm:      # (upper, lower, [centroids], normscale, normoffset), SQ:550-555
+        quant = tuple(quant) + (torch.tensor(1.07), torch.tensor(-0.02))
     n = prefill + steps
     ks = util.k_tokens(n, scale, shift, seed=30 + bits)
     vs = util.v_tokens_no_ties(n, seed=40 + bits)
@@ -36,7 +38,7 @@ def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=2e-3):
     ok, ov = OracleQuantK(rope_theta=10000.0, **kw), OracleQuantV(**kw)
     gk, gv = QuantK(rope_theta=10000.0, device=device, **kw), QuantV(device=device, **kw)
     for c in (ok, ov, gk, gv):
-        c.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        c.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99, norm=norm)
     if prefill:
         kp = ks[:prefill].half().float().t().reshape(H, HD, prefill).contiguous()
         vp = vs[:prefill].half().float().t().reshape(H, HD, prefill).contiguous()
@@ -66,4 +68,6 @@ def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=2e-3):
     assert torch.equal(ov.outlier_indices[:L], gv.outlier_indices[:L].cpu())
     assert torch.equal(ov.outliers[:L].view(torch.int32), gv.outliers[:L].cpu().view(torch.int32))
     assert torch.equal(ov.lookup_table[:L].view(torch.int32), gv.lookup_table[:L].cpu().view(torch.int32))
+    if norm:
+        assert torch.equal(ov.lookup_table2[:L].view(torch.int32), gv.lookup_table2[:L].cpu().view(torch.int32))
     return worst

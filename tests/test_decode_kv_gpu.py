@@ -14,6 +14,17 @@ def test_decode_kv_matches_reference_pipeline(bits, prefill, steps, max_len):
     assert err < 2e-3
 
 
+@pytest.mark.parametrize("bits,prefill", [(2, 20), (2, 0), (3, 24), (4, 24)])
+def test_decode_kv_qnorm(bits, prefill):
+    """K and V Q-Norm through the one-call decode step and the fused prefill packs (ML:486-497, 811-815,
+    1116-1118, 1153-1156, 1237-1240, 1369-1375): at 2 bit both matvecs dequantise with the Q-Norm tables and the V
+    residuals refer to the Q-Norm row; lookup_table2 rows are compared bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    err = decode_check.run(torch.device("cuda:0"), bits=bits, prefill=prefill, steps=4, max_len=64, norm=True)
+    assert err < 2e-3
+
+
 @pytest.mark.parametrize("bits", [4, 3, 2])
 def test_fused_prefill_pack_matches_reference_structure(bits):
     """kvq_pack_{k,v}_fused (one launch for the whole prompt) against the reference-structured prefill

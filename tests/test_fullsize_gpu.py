@@ -15,12 +15,13 @@ L_FULL = 131072 + 77          # ragged last 256-token tile, as on every decode s
 WINDOWS = [(0, 300), (65536 - 100, 333), (L_FULL - 290, 290)]
 
 
-@pytest.fixture(scope="module")
-def big():
+@pytest.fixture(scope="module", params=[4, 3, 2])
+def big(request):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     dev = torch.device("cuda:0")
-    bits, n = 4, 16
+    bits = request.param
+    n = 2 ** bits
     max_len = (L_FULL + 64) // 64 * 64
     g = torch.Generator(device=dev).manual_seed(2024)
     W = HD // 32 * bits
