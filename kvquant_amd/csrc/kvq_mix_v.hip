@@ -37,6 +37,30 @@
 #include "kvq_mix_v_rows.h"
 
 #include <cstdlib>
+#ifndef KVQ_V_WGS
+#define KVQ_V_WGS 512
+#endif
+#ifndef KVQ_V_NOSP
+#define KVQ_V_NOSP 0   // experiment: LDS without the sparse-phase buffers (compile-only occupancy probes)
+#endif
+#ifndef KVQ_V_CT16
+#define KVQ_V_CT16 0
+#endif
+#ifndef KVQ_V_WAVES
+#define KVQ_V_WAVES 4    // waves per SIMD the register allocation aims at
+#endif
+#ifndef KVQ_V_SPREAD
+#define KVQ_V_SPREAD 0   // 1: issue the next chunk's DMA pieces spread over the quads of the math instead of one burst after the barrier (measured: no gain, 88 vs 88 us -- the burst's queueing is hidden by the other waves)
+#endif
+#ifndef KVQ_V_RB
+#define KVQ_V_RB 24
+#endif
+#ifndef KVQ_TRACE
+#define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the chunk loop (tools/dbg/trace_v.py)
+#endif
+#ifndef KVQ_PAD_LDS
+#define KVQ_PAD_LDS 0   // development: extra LDS per workgroup (occupancy experiments)
+#endif
 #ifndef KVQ_V_DBG
 #define KVQ_V_DBG 0   // development ablations (-DKVQ_V_DBG=n): 1 skip the math, 2 skip the DMA, 4 DMA from an L2-resident source
 #endif
@@ -58,7 +82,7 @@ struct VCfg {
   static constexpr int HALVES = BITS == 3 ? 2 : 1;
   static constexpr int CHL = CH / HALVES;              // channels per lane
   static constexpr int SLOTS = NT / (UW * HALVES);     // token slots
-  static constexpr int CT = BITS == 4 ? 32 : 16;       // tokens per chunk (2 bit: 32 needs ~200 VGPRs as unrolled)
+  static constexpr int CT = (BITS == 4 && !KVQ_V_CT16) ? 32 : 16;       // tokens per chunk (2 bit: 32 needs ~200 VGPRs as unrolled)
   static constexpr int QR = CT / 4;                    // 16-byte quads per tile row
   static constexpr int SH = CT == 32 ? 1 : 2;          // log2(tile rows per 256 B)
   static constexpr int ROWS = UW * WORDS;              // tile rows
@@ -70,7 +94,12 @@ struct VCfg {
   static constexpr int QPL = QR / SLOTS;               // quads per lane per chunk
   static constexpr int BUF_B = TILE_B + LUT_B + P_B;   // one pipeline stage
   static constexpr int RED_B = NT * CHL * 4;           // slot reduction (aliases the stages)
-  static constexpr int SMEM_B = (2 * BUF_B > RED_B ? 2 * BUF_B : RED_B);
+  // sparse phase after the loop (aliases the stages): staged probabilities of the workgroup's token share
+  // (37 KB: 288 tokens x 32 heads, odd row stride) + 32 KB of 64-bit accumulators (4096 channels in one pass)
+  static constexpr int SP_P_B = 37888;
+  static constexpr int SP_B = SP_P_B + 32768;
+  static constexpr int SMEM_0 = (2 * BUF_B > RED_B ? 2 * BUF_B : RED_B);
+  static constexpr int SMEM_B = KVQ_V_NOSP ? SMEM_0 : (SMEM_0 > SP_B ? SMEM_0 : SP_B);
   static_assert(QR % SLOTS == 0, "slots must split the chunk's quads");
 };
 
@@ -91,6 +120,9 @@ struct MixArgs {
   int n_units;
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out)
+#if KVQ_TRACE
+  unsigned long long *trace;   // development: [block][wave][chunk][8]
+#endif
 };
 
 // Per-lane constants of the chunk DMA.  Every tile DMA instruction of a wave moves 64/QR consecutive
@@ -108,7 +140,10 @@ struct DmaLane {
 template <int BITS>
 __device__ __forceinline__ DmaLane make_dma_lane() {
   using Cfg = VCfg<BITS>;
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  // (recomputed where it is needed: the asm keeps hipcc from hoisting the rarely taken clamped path's lane
+  //  constants out of the chunk loop, where they would be spilled and reloaded around the DMA issue)
+  asm volatile("" : "+v"(lane));
   const int wave = threadIdx.x >> 6;
   DmaLane d;
   const int s = wave * 64 + lane;              // slot of the wave's first tile instruction
@@ -127,8 +162,12 @@ __device__ __forceinline__ DmaLane make_dma_lane() {
   return d;
 }
 
-// issue the DMA of one chunk (tokens [c0, c0+CT)) into stage `buf`
-template <int BITS>
+// issue the DMA of one chunk (tokens [c0, c0+CT)) into stage `buf`.  PART < 0: everything (the first chunk);
+// PART = q in [0, QPL): the share that is issued at the top of quad q of the previous chunk's math -- tile pieces
+// k with k % QPL == q, and with q == 0 the codebook rows and the probabilities.  Issued in one burst right after
+// the chunk barrier, the 42 pieces of the workgroup's 8 waves queue up behind each other in the CU's memory
+// front end and cost every wave ~1300 cycles per chunk (17 % of the kernel, measured with s_memtime).
+template <int BITS, int PART = -1>
 __device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, uint32_t buf, int64_t c0,
                                             int row_base, int n_rows_valid, int h0, int b) {
   using Cfg = VCfg<BITS>;
@@ -151,6 +190,7 @@ __device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, 
     const uint32_t toff = (uint32_t)(tq + 4 > lim_len ? lim_len - 4 : tq);
 #pragma unroll
     for (int k = 0; k < K_TILE; k++) {
+      if (PART >= 0 && k % Cfg::QPL != PART) continue;
       const int j = wave + k * NW;
       if (j < N_TILE) {
         int r = d.tile_row + k * NW * RPI;
@@ -160,6 +200,7 @@ __device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, 
       }
     }
   }
+  if (PART > 0) return;
   // ---- codebook rows of the chunk
   if ((int)threadIdx.x < LUT_SLOTS) {   // wave-granular: LUT_SLOTS is a multiple of 64 or < 64
     const int tr2 = (int)d.lut_tok < lim_len ? (int)d.lut_tok : lim_len - 1;
@@ -184,6 +225,55 @@ __device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, 
   }
 }
 
+// The common case of issue_chunk -- a chunk that lies entirely inside the rows (c0 + CT <= max_len) and inside the
+// cache (c0 + CT <= L), a full unit group -- needs no clamps: the per-lane part of every source address is a
+// constant of the kernel (three VGPRs), everything that changes with the chunk or the piece goes into the
+// wave-uniform base.  PART as above.  Keeps the register pressure of the math loop low: a spill in there makes
+// hipcc drain the DMAs just issued.
+struct DmaFast {
+  uint32_t tile;   // byte offset of the lane inside every tile piece (the other two are recomputed at the issue)
+};
+
+template <int BITS>
+__device__ __forceinline__ DmaFast make_dma_fast(const MixArgs &a) {
+  using Cfg = VCfg<BITS>;
+  const DmaLane d = make_dma_lane<BITS>();
+  DmaFast f;
+  f.tile = (d.tile_row * (uint32_t)a.max_len + d.tile_q4) * 4u;
+  return f;
+}
+
+template <int BITS, int PART>
+__device__ __forceinline__ void issue_fast(const MixArgs &a, const DmaFast &f, uint32_t buf, int64_t c0,
+                                           int row_base, int h0, int b) {
+  using Cfg = VCfg<BITS>;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int NW = Cfg::NT / 64;
+  constexpr int RPI = 64 / Cfg::QR;
+  constexpr int N_TILE = Cfg::TILE_B / 1024;
+  constexpr int K_TILE = (N_TILE + NW - 1) / NW;
+  constexpr int LUT_SLOTS = Cfg::LUT_B / 16;
+  constexpr int N_P = Cfg::P_B / 256;
+  constexpr int K_P = (N_P + NW - 1) / NW;
+#pragma unroll
+  for (int k = 0; k < K_TILE; k++) {
+    if (k % Cfg::QPL != PART) continue;
+    const int j = wave + k * NW;
+    if (j < N_TILE) dma16(a.mat + (int64_t)(row_base + k * NW * RPI) * a.max_len + c0, f.tile, buf + j * 1024);
+  }
+  if (PART != 0) return;
+  const DmaLane d = make_dma_lane<BITS>();   // (a dozen VALU per chunk; as constants they would cost two VGPRs in the math loop)
+  const uint32_t f_lut = (d.lut_tok * Cfg::N + d.lut_sub) * 4u;
+  const uint32_t f_p = (d.p_head * (uint32_t)a.L + d.p_tok) * 4u;
+  if ((int)threadIdx.x < LUT_SLOTS) dma16(a.lut_rows + c0 * Cfg::N, f_lut, buf + Cfg::TILE_B + wave * 1024);
+#pragma unroll
+  for (int k = 0; k < K_P; k++) {
+    const int j = wave + k * NW;
+    if (j < N_P)
+      dma4(a.p + ((int64_t)b * a.H + h0 + k * NW * (64 / Cfg::CT)) * a.L + c0, f_p, buf + Cfg::TILE_B + Cfg::LUT_B + j * 256);
+  }
+}
+
 template <int BITS, int I, int WORDS>
 __device__ __forceinline__ unsigned vcode(const uint32_t (&w)[WORDS]) {
   if constexpr (BITS == 3) return code_of<3, I>(w);
@@ -192,10 +282,10 @@ __device__ __forceinline__ unsigned vcode(const uint32_t (&w)[WORDS]) {
 }
 
 template <int BITS>
-__global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
+__global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   using Cfg = VCfg<BITS>;
   constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B];  // static: LDS offsets fold into ds immediates
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B + KVQ_PAD_LDS];  // static: LDS offsets fold into ds immediates
   unsigned char *stage0 = smem;
 
   const int tid = threadIdx.x;
@@ -218,9 +308,12 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
   const int64_t t1 = (t0 + a.tr < a.L) ? (t0 + a.tr) : a.L;
   const int n_chunks = (int)((t1 - t0 + CT - 1) / CT);
 
-  const DmaLane dl = make_dma_lane<BITS>();
   const uint32_t lds0 = lds_addr(smem);
-  issue_chunk<BITS>(a, dl, lds0, t0, row_base, n_rows_valid, h0, b);
+  issue_chunk<BITS>(a, make_dma_lane<BITS>(), lds0, t0, row_base, n_rows_valid, h0, b);
+  const DmaFast df = make_dma_fast<BITS>(a);
+  // chunks whose DMA needs no clamps (see issue_fast): all that start before `fast_end`
+  int64_t fast_end = (a.max_len < a.L ? a.max_len : a.L) - CT;
+  if (n_units_valid != Cfg::UW) fast_end = -1;
 
   // ---- sparse residuals ------------------------------------------------------------------------------
   // Workgroup (range, group g) takes the g-th share of the range's TOKENS for ALL channels, so every
@@ -233,33 +326,91 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
   // The sparse phase is bound by memory latency (VALU idle), the dense loop by VALU issue; run AFTER the
   // dense loop it fills the ragged end of the grid (workgroups finish their dense part at different
   // times) instead of stalling every workgroup at once at the start of the kernel (103 -> 97 us at 128K).
+#if KVQ_TRACE
+  unsigned tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned tr_prev;
+  unsigned long long tr_t0, tr_r0;
+  {
+    unsigned long long tt;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+    tr_prev = (unsigned)tt;
+    tr_t0 = tt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_r0)::"memory");
+  }
+#endif
   auto sparse_phase = [&]() {
-    long long *sacc = reinterpret_cast<long long *>(smem + Cfg::BUF_B);
-    constexpr int SCH = (Cfg::SMEM_B - Cfg::BUF_B) / 8;       // channels per pass (>= 4096 for every format)
+    // LDS after the dense loop: [0, SP_P_B) the probabilities of this workgroup's token share for all heads,
+    // [SP_P_B, ...) the fixed-point accumulators.  Staging p (coalesced, independent of the entries) removes the
+    // second dependent memory round trip of the phase (entry -> head -> p gather): the phase is pure latency --
+    // measured 25.8k cycles per wave = 19 % of the kernel at 128K before, with two rounds of two round trips.
+    float *pl = reinterpret_cast<float *>(smem);
+    long long *sacc = reinterpret_cast<long long *>(smem + Cfg::SP_P_B);
+    constexpr int SCH = (Cfg::SMEM_B - Cfg::SP_P_B) / 8;     // channels per pass
     const int64_t share = ((t1 - t0) + a.groups - 1) / a.groups;
     const int64_t s0 = t0 + (int64_t)g * share;
     const int64_t s1 = (s0 + share < t1) ? (s0 + share) : t1;
-    const unsigned nent = s1 > s0 ? (unsigned)(s1 - s0) * (unsigned)a.n_out : 0u;   // < 2^31
+    const int ns = s1 > s0 ? (int)(s1 - s0) : 0;             // tokens of the share
+    const unsigned nent = (unsigned)ns * (unsigned)a.n_out;  // < 2^31
     const float *ov = a.outliers + s0 * a.n_out;
     const int32_t *oi = a.idx + s0 * a.n_out;
     const float *p0 = a.p + s0;
     float *sslab = a.sparse_partial + (int64_t)blockIdx.x * C;
+    const bool staged = ns <= 320 && (int64_t)(ns | 1) * a.H * 4 <= Cfg::SP_P_B;
+    constexpr int RB = KVQ_V_RB;    // entries per lane per round, all loads of a round in flight together (24: a 272-token share at n_out = 42 in one round)
+    auto load_round = [&](unsigned base, int (&row)[RB], float (&val)[RB]) {
+#pragma unroll
+      for (int j = 0; j < RB; j++) {
+        const unsigned e = base + j * Cfg::NT + tid;
+        const unsigned ec = e < nent ? e : (nent ? nent - 1 : 0);
+        row[j] = oi[ec];
+        val[j] = ov[ec];
+      }
+    };
+#if KVQ_TRACE
+    auto sstamp = [&](int k) {
+      unsigned long long tt;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+      tr_acc[k] += (unsigned)tt - tr_prev;
+      tr_prev = (unsigned)tt;
+    };
+#endif
+    int row[RB];
+    float val[RB];
+    if (nent) load_round(0, row, val);         // in flight while the probabilities are staged
+    const int nsp = ns | 1;                     // odd row stride: consecutive heads fall into different LDS banks
+    if (staged) {
+      // wave w stages heads w, w+8, ...; lanes along the tokens (coalesced); all of a lane's loads in flight together
+      const int wv = tid >> 6, ln = tid & 63;
+      for (int hb = 0; hb < a.H; hb += 32) {
+        float v[4][5];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int m = 0; m < 5; m++) {
+            const int h = hb + wv + 8 * k, tl = ln + 64 * m;
+            v[k][m] = (h < a.H && tl < ns) ? p0[(int64_t)h * a.L + tl] : 0.f;
+          }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int m = 0; m < 5; m++) {
+            const int h = hb + wv + 8 * k, tl = ln + 64 * m;
+            if (h < a.H && tl < ns) pl[h * nsp + tl] = v[k][m];
+          }
+      }
+    }
     for (int c0 = 0; c0 < C; c0 += SCH) {
       const int cn = (C - c0 < SCH) ? (C - c0) : SCH;
       for (int i = tid; i < cn; i += Cfg::NT) sacc[i] = 0;
+#if KVQ_TRACE
+      sstamp(6);
+#endif
       __syncthreads();
-      constexpr int RB = BITS == 4 ? 21 : 7;   // entries per lane per round (a 256-token share at n_out = 42 in one round);
-                               // loads are unconditional (clamped index) and issued back to back
+#if KVQ_TRACE
+      sstamp(7);
+#endif
       for (unsigned base = 0; base < nent; base += RB * Cfg::NT) {
-        int row[RB];
-        float val[RB];
-#pragma unroll
-        for (int j = 0; j < RB; j++) {
-          const unsigned e = base + j * Cfg::NT + tid;
-          const unsigned ec = e < nent ? e : nent - 1;
-          row[j] = oi[ec];
-          val[j] = ov[ec];
-        }
+        if (base || c0) load_round(base, row, val);
         float pt[RB];
 #pragma unroll
         for (int j = 0; j < RB; j++) {
@@ -268,7 +419,7 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
           const unsigned tl = __umulhi(ec, a.n_out_magic);
           unsigned h = (unsigned)row[j] >> 7;
           h = h < (unsigned)a.H ? h : (unsigned)a.H - 1u;
-          pt[j] = p0[(int64_t)h * a.L + tl];
+          pt[j] = staged ? pl[h * nsp + tl] : p0[(int64_t)h * a.L + tl];
         }
 #pragma unroll
         for (int j = 0; j < RB; j++) {
@@ -285,9 +436,15 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
           }
         }
       }
+#if KVQ_TRACE
+      sstamp(8);
+#endif
       __syncthreads();
+#if KVQ_TRACE
+      sstamp(9);
+#endif
       for (int i = tid; i < cn; i += Cfg::NT) sslab[c0 + i] = (float)((double)sacc[i] * (1.0 / 4294967296.0));
-      __syncthreads();   // (also frees the region for the pipeline / the next pass)
+      __syncthreads();   // (frees the accumulators for the next pass)
     }
     };
   constexpr int CHL = Cfg::CHL;
@@ -310,10 +467,31 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
   auto chunk = [&](auto STAGE, int ci) {
     constexpr int stage = decltype(STAGE)::value;
     const int64_t c0 = t0 + (int64_t)ci * CT;
+#if KVQ_TRACE
+    auto stamp = [&](int k) {
+      unsigned long long tt;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+      tr_acc[k] += (unsigned)tt - tr_prev;
+      tr_prev = (unsigned)tt;
+    };
+    stamp(0);
+#endif
     dma_wait_all();                       // this wave's DMA pieces of chunk ci have landed
+#if KVQ_TRACE
+    stamp(1);
+#endif
     __syncthreads();                      // ... and everybody else's; the other stage is free again
-    if (ci + 1 < n_chunks && !(KVQ_V_DBG & 2))
-      issue_chunk<BITS>(a, dl, lds0 + (1 - stage) * Cfg::BUF_B, (KVQ_V_DBG & 4) ? t0 : c0 + CT, row_base, n_rows_valid, h0, b);
+#if KVQ_TRACE
+    stamp(2);
+#endif
+    const int64_t cn0 = (KVQ_V_DBG & 4) ? t0 : c0 + CT;          // start of the next chunk
+    const bool more = ci + 1 < n_chunks && !(KVQ_V_DBG & 2);
+    const bool fast = KVQ_V_SPREAD && cn0 <= fast_end;               // (wave-uniform)
+    if (more && !fast)
+      issue_chunk<BITS>(a, make_dma_lane<BITS>(), lds0 + (1 - stage) * Cfg::BUF_B, cn0, row_base, n_rows_valid, h0, b);
+#if KVQ_TRACE
+    stamp(3);
+#endif
     const unsigned char *tile = smem + stage * Cfg::BUF_B;
     const unsigned char *lutb = smem + stage * Cfg::BUF_B + Cfg::TILE_B;
     float *pb = reinterpret_cast<float *>(smem + stage * Cfg::BUF_B + Cfg::TILE_B + Cfg::LUT_B);
@@ -332,6 +510,8 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
     }
     static_for<0, Cfg::QPL>([&](auto QQ) {
       constexpr int qq = decltype(QQ)::value;
+      // the next chunk's DMA, a quad's share at a time (the other stage is free since the barrier above)
+      if (more && fast) issue_fast<BITS, qq>(a, df, lds0 + (1 - stage) * Cfg::BUF_B, cn0, row_base, h0, b);
       const int q = sl * Cfg::QPL + qq;
       uint4 wq[WORDS];
 #pragma unroll
@@ -386,6 +566,10 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
                                                // flight at a time (VGPR budget)
       });
     });
+#if KVQ_TRACE
+    asm volatile("" :: "v"(acc[0]));
+    stamp(4);
+#endif
   };
   for (int ci = 0; ci < n_chunks; ci += 2) {
     chunk(std::integral_constant<int, 0>{}, ci);
@@ -411,10 +595,34 @@ __global__ __launch_bounds__(512, 4) void mix_v_kernel(MixArgs a) {
 #pragma unroll
     for (int i = 0; i < CHL; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
   }
+#if KVQ_TRACE
+  {
+    unsigned long long tt;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+    tr_acc[5] += (unsigned)tt - tr_prev;   // slot reduce + partial store
+    tr_prev = (unsigned)tt;
+  }
+#endif
   if (sparse) {
     __syncthreads();   // the slot reduction is done with the LDS
     sparse_phase();
   }
+#if KVQ_TRACE
+  {
+    unsigned long long tt;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+    if ((tid & 63) == 0 && blockIdx.x < 512) {
+      unsigned long long *tr = a.trace + ((int64_t)blockIdx.x * 8 + (tid >> 6)) * 16;
+      for (int k = 0; k < 10; k++) tr[k] = tr_acc[k];
+      tr[10] = (unsigned)tt - tr_prev;   // rest of the sparse phase (slab write)
+      tr[11] = n_chunks;
+      unsigned long long rr;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr)::"memory");
+      tr[12] = tt - tr_t0;               // shader clocks of the wave
+      tr[13] = rr - tr_r0;               // 100 MHz ticks of the wave
+    }
+  }
+#endif
 }
 
 // mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  32 channels x 32 range lanes per block (the pass is
@@ -467,7 +675,7 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   Plan pl;
   pl.n_units = H * Cfg::UPH;
   pl.groups = (pl.n_units + Cfg::UW - 1) / Cfg::UW;
-  int64_t want = 512 / pl.groups;   // two 512-lane workgroups per CU
+  int64_t want = KVQ_V_WGS / pl.groups;   // KVQ_V_WGS / 256 workgroups of 512 lanes per CU
   if (want < 1) want = 1;
   int64_t tr = (L + want - 1) / want;
   tr = (tr + Cfg::CT - 1) / Cfg::CT * Cfg::CT;
@@ -574,6 +782,10 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
   a.n_units = 0;
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
+#if KVQ_TRACE
+  a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
+  if (!a.trace) return KVQ_EINVAL;
+#endif
   switch (bits) {
     case 4: return launch_mix<4>(a, mul, accumulate, st);
     case 3: return launch_mix<3>(a, mul, accumulate, st);

@@ -46,6 +46,12 @@
 #ifndef KVQ_ABL
 #define KVQ_ABL 0      // ablation builds (tools/abl): timing experiments, results are wrong by construction
 #endif
+#ifndef KVQ_TRACE
+#define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the head loop (tools/dbg/trace_k.py)
+#endif
+#ifndef KVQ_PAD_LDS
+#define KVQ_PAD_LDS 0   // development: extra LDS per workgroup (occupancy experiments)
+#endif
 #ifndef KVQ_K_TMASK
 #define KVQ_K_TMASK (-1)   // development: AND-mask on the token of the packed-word loads (L2-resident source)
 #endif
@@ -80,6 +86,9 @@ struct ScoreKArgs {
   float sm_inv;
   int sm_nparts;
   float rope_theta;
+#if KVQ_TRACE
+  unsigned long long *trace;   // development: [block][wave][head][8] cycle stamps
+#endif
 };
 
 // BITS consecutive word-rows starting at uniform row `row0`, each read at the lane's byte offset `voff`:
@@ -140,7 +149,7 @@ void score_k_kernel(ScoreKArgs a) {
   // q of the group's heads for the sparse phase: 16 KB.  With 4-bit tables it aliases table buffer 1, which
   // is first written (by the DMA for the second head) after the sparse phase; smaller tables leave room.
   constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PF * TAB_B + SC_B + QL_B];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PF * TAB_B + SC_B + QL_B + KVQ_PAD_LDS];
   unsigned char *lutq = smem;                                                    // [PF][TAB_B]
   float *sc = reinterpret_cast<float *>(smem + PF * TAB_B);                      // [T][SCS]
   float *ql = reinterpret_cast<float *>(smem + PF * TAB_B + SC_B);               // [hpg][128]
@@ -388,6 +397,12 @@ void score_k_kernel(ScoreKArgs a) {
     const int h = h0 + hh;
     uint32_t (&wlo)[BITS] = wlo_all[buf];
     uint32_t (&whi)[BITS] = whi_all[buf];
+#if KVQ_TRACE
+    unsigned long long *tr = a.trace + (((int64_t)blockIdx.x * NWAVES + wave) * 32 + hh) * 8;
+    const bool trw = lane == 0 && blockIdx.x < 1024 && hh < 32;
+    auto stamp = [&](int k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tt = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); if (trw) tr[k] = tt; };
+    stamp(0);
+#endif
     // this head's table and words were requested PF-1 heads ago; younger requests may stay in flight
     if (PF > 2 && hh + 1 < nh) {
       if (acc_dense) vm_wait<(PF - 2) * (STEP_OPS + 1)>();
@@ -395,10 +410,19 @@ void score_k_kernel(ScoreKArgs a) {
     } else {
       vm_wait<0>();
     }
+#if KVQ_TRACE
+    stamp(1);
+#endif
 #if !(KVQ_ABL & 2)
     __syncthreads();  // ... landed for all waves (and sc complete); table buffer `nxt` is free
 #endif
+#if KVQ_TRACE
+    stamp(2);
+#endif
     if (hh + PF - 1 < nh) fetch_head(hh + PF - 1, std::integral_constant<int, nxt>{});
+#if KVQ_TRACE
+    stamp(3);
+#endif
     const unsigned char *tlo = lutq + buf * TAB_B;
     const unsigned char *thi = lutq + buf * TAB_B + KTab<BITS>::HALF_B;
     // 16 look-ups (8 pairs) are issued back to back before their 16 packed FMAs, into 4 independent
@@ -466,6 +490,10 @@ void score_k_kernel(ScoreKArgs a) {
     const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     float res = acc.x + acc.y;
     res += __shfl_xor(res, 32);
+#if KVQ_TRACE
+    asm volatile("" :: "v"(res));
+    stamp(4);
+#endif
     if constexpr (SPARSE) {
       // scores of the tile collect in LDS (dense part here, sparse runs whenever their chunk comes up) and
       // are written out once after the last head
@@ -492,6 +520,9 @@ void score_k_kernel(ScoreKArgs a) {
         __builtin_nontemporal_store(res, dst);
       }
     }
+#if KVQ_TRACE
+    stamp(5);
+#endif
   };
   for (int hb = 0; hb < nh; hb += PF) {
     static_for<0, PF>([&](auto U) {
@@ -630,6 +661,10 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   dim3 grid((unsigned)(a.full_blocks + tail_blocks), 1, q_len), block(NWAVES * 64);
   if (a.sm_parts != nullptr && (!SPARSE || a.sm_nparts != (int)((a.L + T - 1) / T))) return KVQ_EINVAL;
   a.rope_theta = rope_theta;
+#if KVQ_TRACE
+  a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
+  if (!a.trace) return KVQ_EINVAL;
+#endif
   score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED><<<grid, block, 0, st>>>(a);
   return check_launch();
 }

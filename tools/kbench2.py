@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Per-launch timing of the DECODE variants of the hot-path kernels on one layer (development tool): decode
+prologue, score kernel (query-premultiplied tables, token-contiguous outlier mirror, fused softmax partials),
+softmax finish, p.V.  Two layer-sized caches alternate so that nothing is served from the 256 MB Infinity Cache.
+usage: [KVQ_LIB=tools/abl/libkvq_X.so] python tools/kbench2.py [bits] [L ...]"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+if os.environ.get("KVQ_LIB"):
+    import kvquant_amd._lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["KVQ_LIB"])
+from kvquant_amd import ops  # noqa: E402
+
+H, HD, C = 32, 128, 4096
+
+
+def run(bits, L, iters=30, nrot=2):
+    n = 2 ** bits
+    W = HD // 32 * bits
+    max_len = (L + 64 + 63) // 64 * 64
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    caches = []
+    for _ in range(nrot):
+        d = {}
+        d["k"] = torch.randint(-2 ** 31, 2 ** 31 - 1, (H, W, max_len), device=dev, dtype=torch.int64, generator=g).to(torch.int32)
+        d["v"] = torch.randint(-2 ** 31, 2 ** 31 - 1, (H, W, max_len), device=dev, dtype=torch.int64, generator=g).to(torch.int32)
+        d["rows"] = torch.randn(max_len, n, device=dev, generator=g).sort(dim=-1).values.contiguous()
+        for nm in ("k", "v"):
+            d[nm + "vals"] = torch.randn(max_len, 42, device=dev, generator=g)
+            d[nm + "idx"] = torch.sort(torch.randint(0, C, (max_len, 42), device=dev, generator=g), dim=-1).values.to(torch.int32)
+        d["kvals_t"] = d["kvals"].t().contiguous()
+        d["kidx_t"] = d["kidx"].t().contiguous()
+        caches.append(d)
+    lut = torch.randn(H, HD, n, device=dev, generator=g).sort(dim=-1).values.contiguous()
+    q = torch.randn(1, H, HD, device=dev, generator=g)
+    inv = 1.0 / math.sqrt(HD)
+    s = torch.zeros(1, H, L, device=dev)
+    out = torch.zeros(1, H, HD, device=dev)
+    # tables of q into the score workspace
+    ops.score_k(bits, q, caches[0]["k"], torch.zeros(1, H, 1, device=dev), lut, 1, 10000.0, 0, accumulate=False)
+    ws = ops._workspace(dev, ops._L().kvq_score_k_workspace_bytes(bits, 1, H), slot="score")
+    n_parts = ops._L().kvq_score_k_softmax_parts(bits, L, 1)
+    state = {}
+
+    def kcall(i):
+        d = caches[i % nrot]
+        state["parts"] = ops.score_k_prepared_softmax(bits, d["k"], s, lut, L, 10000.0, 0, ws, d["kvals"], d["kidx"], inv,
+                                                      n_parts, d["kvals_t"], d["kidx_t"])
+
+    def fcall(i):
+        state["p"], _ = ops.softmax_finish(s[0], state["parts"], n_parts, inv)
+
+    def vcall(i):
+        d = caches[i % nrot]
+        ops.mix_v(bits, state["p"].unsqueeze(0), d["v"], out, d["rows"], L, d["vvals"], d["vidx"], accumulate=False)
+
+    res = {}
+    for nm, fn, bpt in (("score_k", kcall, C * bits // 8 + 336 + 128), ("softmax_finish", fcall, 256),
+                        ("mix_v", vcall, C * bits // 8 + 336 + 4 * n + 128)):
+        for i in range(3):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000 / iters
+        res[nm] = us
+        print("%s bits=%d L=%7d %-15s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)"
+              % (os.environ.get("KVQ_LIB", "libkvq").split("/")[-1], bits, L, nm, us, L * bpt / us / 1e3, L * bpt / us / 1e3 / 80), flush=True)
+    return res
+
+
+if __name__ == "__main__":
+    bits = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    for L in [int(a) for a in sys.argv[2:]] or [131072 + 77]:
+        run(bits, L)

@@ -1,0 +1,97 @@
+// microbenchmark 3: the inner step of the two decode matvecs in isolation (development tool).
+//   per code:  field extraction (v_bfe_u32) -> LDS look-up (ds_read_b32 / b64) -> FMA (v_fmac_f32 / v_pk_fma_f32)
+// 8 codes per batch, the 8 look-ups of a batch in flight together (as the kernels do).  Reports ns per code-step per
+// SIMD at 4 and 2 waves per SIMD, for the VALU part alone, the LDS part alone and both -- i.e. what the instruction
+// mix itself allows on gfx950, before any memory traffic, barriers or sparse work.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed) {
+  __shared__ __attribute__((aligned(16))) float tab[4096];
+  for (int i = threadIdx.x; i < 4096; i += 512) tab[i] = (float)i * 0.001f;
+  __syncthreads();
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+  f32x2 p0 = {0, 0}, p1 = p0, p2 = p0, p3 = p0;
+  f32x2 cs = {0.5f, 0.25f};
+  unsigned w = (threadIdx.x * 2654435761u) ^ seed;
+  const float pt = 0.37f;
+  unsigned u0, u1, u2, u3, u4, u5, u6, u7;
+  float v0, v1, v2, v3, v4, v5, v6, v7;
+  f32x2 q0, q1, q2, q3, q4, q5, q6, q7;
+  const unsigned we = (w << 2) & 0x3C3C3C3Cu, wo = (w >> 2) & 0x3C3C3C3Cu;
+  const unsigned ke = (w << 3) & 0x78787878u, ko = (w >> 1) & 0x78787878u;
+  for (int it = 0; it < iters; it++) {
+    if (MODE == 0 || MODE == 2) {   // extraction (V kernel form: bytes of two pre-masked words)
+      asm volatile("v_and_b32 %0, 0xff, %8\n v_and_b32 %1, 0xff, %9\n v_bfe_u32 %2, %8, 8, 8\n v_bfe_u32 %3, %9, 8, 8\n"
+                   "v_bfe_u32 %4, %8, 16, 8\n v_bfe_u32 %5, %9, 16, 8\n v_lshrrev_b32 %6, 24, %8\n v_lshrrev_b32 %7, 24, %9\n"
+                   : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3), "=v"(u4), "=v"(u5), "=v"(u6), "=v"(u7) : "v"(we), "v"(wo));
+    }
+    if (MODE == 1) { u0 = we & 0xff; u1 = wo & 0xff; u2 = u0; u3 = u1; u4 = u0; u5 = u1; u6 = u0; u7 = u1; }
+    if (MODE == 1 || MODE == 2) {   // 8 x ds_read_b32 in flight
+      asm volatile("ds_read_b32 %0, %8 offset:0\n ds_read_b32 %1, %9 offset:64\n ds_read_b32 %2, %10 offset:128\n ds_read_b32 %3, %11 offset:192\n"
+                   "ds_read_b32 %4, %12 offset:256\n ds_read_b32 %5, %13 offset:320\n ds_read_b32 %6, %14 offset:384\n ds_read_b32 %7, %15 offset:448\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                   : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(u4), "v"(u5), "v"(u6), "v"(u7) : "memory");
+    }
+    if (MODE == 0) { v0 = __uint_as_float(u0); v1 = __uint_as_float(u1); v2 = __uint_as_float(u2); v3 = __uint_as_float(u3); v4 = __uint_as_float(u4); v5 = __uint_as_float(u5); v6 = __uint_as_float(u6); v7 = __uint_as_float(u7); }
+    if (MODE == 0 || MODE == 2) {
+      asm volatile("v_fmac_f32 %0, %8, %16\n v_fmac_f32 %1, %9, %16\n v_fmac_f32 %2, %10, %16\n v_fmac_f32 %3, %11, %16\n"
+                   "v_fmac_f32 %4, %12, %16\n v_fmac_f32 %5, %13, %16\n v_fmac_f32 %6, %14, %16\n v_fmac_f32 %7, %15, %16\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                   : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(pt));
+    }
+    if (MODE == 1) { a0 += v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7; }
+    // ---- K kernel form: ds_read_b64 + v_pk_fma_f32
+    if (MODE == 3 || MODE == 5) {
+      asm volatile("v_and_b32 %0, 0xff, %8\n v_and_b32 %1, 0xff, %9\n v_bfe_u32 %2, %8, 8, 8\n v_bfe_u32 %3, %9, 8, 8\n"
+                   "v_bfe_u32 %4, %8, 16, 8\n v_bfe_u32 %5, %9, 16, 8\n v_lshrrev_b32 %6, 24, %8\n v_lshrrev_b32 %7, 24, %9\n"
+                   : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3), "=v"(u4), "=v"(u5), "=v"(u6), "=v"(u7) : "v"(ke), "v"(ko));
+    }
+    if (MODE == 4) { u0 = ke & 0xff; u1 = ko & 0xff; u2 = u0; u3 = u1; u4 = u0; u5 = u1; u6 = u0; u7 = u1; }
+    if (MODE == 4 || MODE == 5) {
+      asm volatile("ds_read_b64 %0, %8 offset:0\n ds_read_b64 %1, %9 offset:256\n ds_read_b64 %2, %10 offset:512\n ds_read_b64 %3, %11 offset:768\n"
+                   "ds_read_b64 %4, %12 offset:1024\n ds_read_b64 %5, %13 offset:1280\n ds_read_b64 %6, %14 offset:1536\n ds_read_b64 %7, %15 offset:1792\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(q4), "=v"(q5), "=v"(q6), "=v"(q7)
+                   : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(u4), "v"(u5), "v"(u6), "v"(u7) : "memory");
+    }
+    if (MODE == 3) { q0.x = __uint_as_float(u0); q1.x = __uint_as_float(u1); q2.x = __uint_as_float(u2); q3.x = __uint_as_float(u3); q4.x = __uint_as_float(u4); q5.x = __uint_as_float(u5); q6.x = __uint_as_float(u6); q7.x = __uint_as_float(u7);
+                     q0.y = q1.y = q2.y = q3.y = q4.y = q5.y = q6.y = q7.y = 1.f; }
+    if (MODE == 3 || MODE == 5) {
+      asm volatile("v_pk_fma_f32 %0, %4, %12, %0\n v_pk_fma_f32 %1, %5, %12, %1\n v_pk_fma_f32 %2, %6, %12, %2\n v_pk_fma_f32 %3, %7, %12, %3\n"
+                   "v_pk_fma_f32 %0, %8, %12, %0\n v_pk_fma_f32 %1, %9, %12, %1\n v_pk_fma_f32 %2, %10, %12, %2\n v_pk_fma_f32 %3, %11, %12, %3\n"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+                   : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(cs));
+    }
+    if (MODE == 4) { p0 += q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7; }
+  }
+  float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (p0 + p1 + p2 + p3).x + (p0 + p1 + p2 + p3).y;
+  if (s == 12345.678f) out[0] = s;
+}
+template <int MODE>
+static void run(const char *name, float *d, int blocks) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  int iters = 20000;
+  float ms = 0;
+  for (int rep = 0; rep < 2; rep++) {
+    hipEventRecord(e0);
+    k<MODE><<<blocks, 512>>>(d, iters, 12345u);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  double steps_per_simd = (blocks / 256.0) * 2.0 * iters * 8.0;   // waves per SIMD x code steps per wave
+  printf("%-44s %d waves/SIMD: %8.3f ms -> %6.2f ns per code-step per SIMD (%.2f per wave)\n", name, blocks / 128, ms,
+         ms * 1e6 / steps_per_simd, ms * 1e6 / (iters * 8.0));
+}
+#define RUN(M, NAME) run<M>(NAME, d, 512); run<M>(NAME, d, 256);
+int main() {
+  float *d; hipMalloc(&d, 4096);
+  RUN(0, "V form: bfe/and/lshr + v_fmac (no LDS)") RUN(1, "V form: 8 x ds_read_b32 only") RUN(2, "V form: extraction + ds_read_b32 + v_fmac")
+  RUN(3, "K form: bfe/and/lshr + v_pk_fma (no LDS)") RUN(4, "K form: 8 x ds_read_b64 only") RUN(5, "K form: extraction + ds_read_b64 + v_pk_fma")
+  printf("budget of the kernels at 128K: q.K^T 87 us and p.V 82 us over 8192 code-steps per SIMD = 10.6 / 10.0 ns per code-step\n");
+  return 0;
+}
