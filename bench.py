@@ -11,11 +11,16 @@ row, pack, outlier row) -> p.V + sparse.  Inputs (q, k, v per layer: synthetic
 fp16 activations) and the caches are resident in HBM before the timed region.
 The model's linear layers are NOT part of this path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--ctx 131072] [--bits 4]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--ctx 131072] [--bits 4] [--sinks 0]
+  python bench.py --sweep          # one JSON line per BASELINE configuration (4K hot/rotated, 32K, 128K, 1M;
+                                   # nuq4 and nuq3 + 5 sinks), the default line last
 
-N > 1 (torchrun): every rank runs an independent decode stream (its own 32-layer
-cache) -- the path has no data-path collective; value = N streams' tokens / max
-time over ranks (weak scaling).
+N > 1 (torchrun, one rank per GPU): the caches are SHARDED BY LAYER over the ranks exactly like the reference's
+set_devices (modeling_llama.py:2428-2453) and N decode streams are kept in flight through the N pipeline stages;
+the 8 KB activation moves between neighbouring ranks point-to-point over RCCL (no collective on the data path).
+Per-GPU work is fixed as N grows (32/N layers x N streams x ctx): weak scaling, value = all streams' tokens per
+second.  --streams 1 is the reference's capacity mode (one long-context stream); --replicas keeps the old
+"N independent 32-layer copies" mode.
 """
 import argparse
 import json
@@ -32,6 +37,7 @@ sys.path.insert(0, ROOT)
 H, HD, C = 32, 128, 4096
 N_LAYERS = 32
 THETA = 10000.0
+TRAFFIC_PROFILE = "profiles/pmc_traffic.json"
 
 
 def parse():
@@ -44,7 +50,12 @@ def parse():
     ap.add_argument("--layers", type=int, default=N_LAYERS)
     ap.add_argument("--sinks", type=int, default=0,
                     help="first_few_fp16 attention-sink tokens kept in fp16 (BASELINE config 3: --bits 3 --sinks 5)")
+    ap.add_argument("--streams", type=int, default=0, help="decode streams in flight (default: one per rank)")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent full copies instead of layer sharding")
+    ap.add_argument("--sweep", action="store_true", help="every BASELINE configuration, one JSON line each (1 GPU)")
+    ap.add_argument("--retrieval", action="store_true", help="plant a retrievable token and check it (config 5 proxy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp16-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=16384)
     return ap.parse_args()
 
@@ -72,6 +83,15 @@ def synth_tokens(S, scale, shift, gen, dev):
     return k.half(), v.half()
 
 
+def rope_rotate(x, pos, sign=1.0):
+    """RoPE (rotate-half convention of the reference, ML:180-205) of x [H, hd] at position pos; sign = -1 inverts"""
+    inv = 1.0 / (THETA ** (torch.arange(0, HD, 2, device=x.device, dtype=torch.float32) / HD))
+    ang = torch.cat((inv, inv)) * float(pos) * sign
+    x = x.float()
+    rot = torch.cat((-x[..., HD // 2:], x[..., :HD // 2]), dim=-1)
+    return x * ang.cos() + rot * ang.sin()
+
+
 class Layer:
     def __init__(self, bits, max_len, gen, dev, sinks=0):
         from kvquant_amd.cache import QuantK, QuantV
@@ -84,6 +104,7 @@ class Layer:
         self.k.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
         self.v.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
         self.sinks = sinks
+        self.planted = None
         if sinks:
             # the first tokens stay in fp16 (post-RoPE keys), ML:1464-1466; their scores / outputs are two tiny
             # fp16 matmuls around the compressed path, as in the reference (ML:1950-1962, 1987-1995)
@@ -92,30 +113,31 @@ class Layer:
             self.k.klen += sinks
             self.v.vlen += sinks
 
-    def fill(self, ctx, gen, dev, chunk=8192):
+    def fill(self, ctx, gen, dev, chunk=8192, plant=None):
+        """prefill-pack ctx synthetic tokens; plant = (position, key [C], value [C]) replaces one of them"""
         done = 0
         while done < ctx:
             S = min(chunk, ctx - done)
             k, v = synth_tokens(S, self.scale, self.shift, gen, dev)
+            if plant is not None and done <= plant[0] < done + S:
+                k[plant[0] - done] = plant[1].half()
+                v[plant[0] - done] = plant[2].half()
+                self.planted = plant[0]
             self.k.parallel_pack(k.view(S, H, HD).permute(1, 2, 0))
             self.v.parallel_pack(v.view(S, H, HD).permute(1, 2, 0))
             done += S
 
 
-def decode_step(layers, qs, ks, vs, step):
-    """one token through every layer's KV path (GPU-resident: 5 launches per layer, no host sync, fp16
-    activations consumed directly); returns the last attention output"""
+def layer_step(lay, q, k, v):
+    """one token through one layer's KV path (GPU-resident: 5 launches, no host sync, fp16 activations consumed
+    directly); returns the attention output f32 [1, H, hd]"""
     from kvquant_amd.cache import decode_kv
-    out = None
-    for li, lay in enumerate(layers):
-        if lay.sinks:
-            q = qs[li][step]
-            sink_scores = (torch.bmm(q.unsqueeze(1), lay.k_sink) / math.sqrt(HD)).squeeze(1)        # f16 [H, n_sink]
-            out, sp = decode_kv(lay.k, lay.v, q, ks[li][step], vs[li][step], sink_scores)
-            out = out + torch.bmm(sp.unsqueeze(1), lay.v_sink).transpose(0, 1).float()
-            continue
-        out, _ = decode_kv(lay.k, lay.v, qs[li][step], ks[li][step], vs[li][step])   # f32 [1,H,hd]
-    return out.half()
+    if lay.sinks:
+        sink_scores = (torch.bmm(q.unsqueeze(1), lay.k_sink) / math.sqrt(HD)).squeeze(1)        # f16 [H, n_sink]
+        out, sp = decode_kv(lay.k, lay.v, q, k, v, sink_scores)
+        return out + torch.bmm(sp.unsqueeze(1), lay.v_sink).transpose(0, 1).float()
+    out, _ = decode_kv(lay.k, lay.v, q, k, v)
+    return out
 
 
 class KernelTimers:
@@ -173,12 +195,48 @@ def algorithmic_bytes(bits, L, kernel):
 
 
 def cpu_baseline(bits, sample_tokens, ctx, layers):
-    """The reference's CPU path = simulated quantisation (quant/kvquant/
-    simquant_module_quantizer.py) feeding ordinary fp32 attention.  Timed here: one
-    layer's decode step over `sample_tokens` reconstructed tokens with the C oracle
-    (OpenMP over the host cores), scaled linearly to ctx tokens x layers."""
+    """The reference's CPU path = simulated quantisation (quant/kvquant/simquant_module_quantizer.py:
+    QuantLinearSim fake-quantises the k_proj / v_proj outputs) feeding ordinary fp32 attention.  Two legs on the host
+    cores, bounded samples scaled linearly (~10 s each):
+      quantize  -- the reference's own torch formulation (restated in oracle/simquant.py, bit-exact vs the reference
+                   module): per-channel capped-outlier K and per-token dynamic V fake-quant of a block of tokens;
+                   a decode step quantizes ONE new token per layer, a prefill all of them;
+      attention -- fp32 RoPE + q.K^T + softmax + p.V over the reconstructed tokens of one layer (C / OpenMP port)."""
     from oracle import ckernels as ck
+    from oracle import simquant as sq
+    cores = os.cpu_count() or 1
+    qthreads = min(cores, 16)        # (torch's CPU kernels lose throughput to oversubscription on 100+ core hosts:
+    torch.set_num_threads(qthreads)  #  measured 37 s per 512-token block with 256 threads vs 1 s with 16)
     g = torch.Generator().manual_seed(0)
+    # ---- quantize leg
+    n = 2 ** bits
+    scale = torch.exp(0.5 * torch.randn(C, generator=g))
+    quant = ((2.576 * scale).numpy()[None], (-2.576 * scale).numpy()[None],
+             [torch.sort(torch.rand(n, generator=g) * 2 - 1).values.numpy().reshape(n, 1)])
+    blk = 512
+    kb = (torch.randn(blk, C, generator=g) * scale).half()
+    vb = torch.randn(blk, C, generator=g).half()
+    sq.fake_quant_k(kb[:8], quant, bits)
+    t0 = time.time()
+    qreps = 0
+    while True:
+        sq.fake_quant_k(kb, quant, bits, cap_outliers=21)
+        sq.fake_quant_v(vb, quant, bits, sparsity_threshold=0.99)
+        qreps += 1
+        if time.time() - t0 > 8.0 or qreps >= 200:
+            break
+    q_total = time.time() - t0
+    prefill_tok_s = qreps * blk / q_total / layers           # tokens/s through all layers' K and V
+    t1 = time.time()
+    one = 0
+    while True:
+        sq.fake_quant_k(kb[:1], quant, bits, cap_outliers=21)
+        sq.fake_quant_v(vb[:1], quant, bits, sparsity_threshold=0.99)
+        one += 1
+        if time.time() - t1 > 2.0 or one >= 2000:
+            break
+    q_one = (time.time() - t1) / one                          # one new token, one layer
+    # ---- attention leg
     khat = torch.randn(sample_tokens, C, generator=g)
     vhat = torch.randn(sample_tokens, C, generator=g)
     q = torch.randn(C, generator=g)
@@ -192,11 +250,214 @@ def cpu_baseline(bits, sample_tokens, ctx, layers):
             break
     total = time.time() - t0
     dt = total / reps
-    step_s = dt * (ctx / sample_tokens) * layers
-    return {"value": 1.0 / step_s, "unit": "tokens/s", "cores": ck.num_threads(), "kind": "port",
-            "sample": "%d x (1 layer x %d reconstructed tokens: fp32 RoPE+qK^T+softmax+pV, oracle C/OpenMP) = %.1f s of "
-                      "CPU work, %.3f s each, scaled x%g tokens x%d layers"
-                      % (reps, sample_tokens, total, dt, ctx / sample_tokens, layers)}
+    step_s = (dt * (ctx / sample_tokens) + q_one) * layers
+    return {"value": 1.0 / step_s, "unit": "tokens/s", "cores": ck.num_threads(), "host_cores": cores, "kind": "port",
+            "prefill_quantize_tokens_per_s": prefill_tok_s,
+            "sample": "attention: %d x (1 layer x %d reconstructed tokens: fp32 RoPE+qK^T+softmax+pV, oracle C/OpenMP, %d "
+                      "threads) = %.1f s, %.3f s each, scaled x%g tokens x%d layers; quantize: %d x (%d-token block, "
+                      "per-channel capped K + per-token dynamic V fake-quant, torch CPU on %d threads = the reference's formulation) = "
+                      "%.1f s -> %.0f prompt tokens/s through %d layers; one new token per layer per decode step = %.2f ms"
+                      % (reps, sample_tokens, ck.num_threads(), total, dt, ctx / sample_tokens, layers, qreps, blk,
+                         qthreads, q_total, prefill_tok_s, layers, q_one * 1e3)}
+
+
+def fp16_matvec_baseline(ctx, dev, iters=10):
+    """The un-quantised baseline of the reference's kernel benchmarks (benchmarking/scripts/test_kernel_baselines.py:
+    28-61): fp16 K / V of one layer, torch.matmul for q.K^T and p.V (rocBLAS batched GEMV), two copies alternating."""
+    try:
+        ks = [torch.randn(H, ctx, HD, device=dev, dtype=torch.float16) for _ in range(2)]
+        vs = [torch.randn(H, ctx, HD, device=dev, dtype=torch.float16) for _ in range(2)]
+    except torch.cuda.OutOfMemoryError:
+        return None
+    q = torch.randn(H, 1, HD, device=dev, dtype=torch.float16)
+    p = torch.softmax(torch.randn(H, 1, ctx, device=dev), dim=-1).half()
+    res = {}
+    for name, fn in (("qk", lambda i: torch.matmul(q, ks[i % 2].transpose(1, 2))), ("pv", lambda i: torch.matmul(p, vs[i % 2]))):
+        for i in range(3):
+            fn(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name + "_us"] = e0.elapsed_time(e1) * 1000.0 / iters
+    byts = ctx * C * 2
+    res["bytes_per_token"] = 2 * C * 2
+    res["qk_GBps"] = byts / res["qk_us"] / 1e3
+    res["pv_GBps"] = byts / res["pv_us"] / 1e3
+    del ks, vs
+    return res
+
+
+def check_retrieval(lay, q, dev):
+    """SURVEY 8(d) config 5 proxy for the passkey evaluation: one cached token was planted whose key is aligned with
+    the (de-rotated) query.  Per head: the softmax mass the decode step gives that token (from the path's own
+    probabilities) and, where the mass is ~1, the attention output against that token's dequantised value (the p.V
+    kernel on a one-hot probability vector).  Retrieved = mass > 0.999; the synthetic keys are heavy-tailed
+    (1 % of the entries x6), so a few heads may see a competitor."""
+    from kvquant_amd import ops
+    from kvquant_amd.cache import decode_kv
+    kc, vc = lay.k, lay.v
+    L = kc.klen - kc.first_few_fp16
+    g = torch.Generator(device=dev).manual_seed(99)
+    knew = torch.zeros(C, device=dev, dtype=torch.float16)
+    vnew = torch.randn(C, device=dev, dtype=torch.float16, generator=g)
+    out, _ = decode_kv(kc, vc, q, knew, vnew)                          # appends one more token (score ~ 0)
+    s = torch.zeros(1, H, L + 1, device=dev)
+    ops.score_k(kc.bits, q.float().unsqueeze(0).contiguous(), kc.kcache, s, kc.lookup_table, L + 1, THETA,
+                kc.first_few_fp16, kc.outliers, kc.outlier_indices, accumulate=False)
+    probs, _ = ops.softmax_scale(s[0], 1.0 / math.sqrt(HD))
+    mass = probs[:, lay.planted]
+    onehot = torch.zeros(1, H, L + 1, device=dev)
+    onehot[:, :, lay.planted] = 1.0
+    ref = torch.empty(1, H, HD, device=dev)
+    ops.mix_v(vc.bits, onehot, vc.vcache, ref, vc.mix_table(), L + 1, vc.outliers, vc.outlier_indices, accumulate=False)
+    hit = mass > 0.999
+    err = float(((out - ref)[0][hit].abs().amax() / ref[0][hit].abs().amax())) if bool(hit.any()) else None
+    top1 = int((probs.argmax(dim=-1) == lay.planted).sum())
+    return {"planted_at": lay.planted, "context": L + 1, "heads_top1": top1, "heads_mass_gt_0.999": int(hit.sum()),
+            "min_mass": float(mass.min()), "max_rel_err_vs_dequantised_value": err,
+            "ok": top1 >= (3 * H) // 4 and err is not None and err < 5e-3}
+
+
+def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
+    """build the caches of one configuration, time args.steps decode steps, return the result dict (rank 0) or None"""
+    from kvquant_amd import sharding
+    total = args.steps + args.warmup
+    max_len = (args.ctx + total + 8 + 63) // 64 * 64
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    sharded = world > 1 and not args.replicas
+    streams = args.streams if args.streams > 0 else (world if sharded else 1)
+    owned = sharding.layer_assignment(args.layers, world)[rank] if sharded else list(range(args.layers))
+    t_setup = time.time()
+    caches, qs, ks, vs = {}, {}, {}, {}
+    plant_q = None
+    for s in range(streams):
+        for li in owned:
+            lay = Layer(args.bits, max_len, gen, dev, args.sinks)
+            plant = None
+            if args.retrieval and li == owned[0] and s == 0:
+                # query 3x the usual norm at the decode position; the planted key is the query rotated back to its
+                # own position (pre-RoPE).  Most of its channels saturate at the quantiser's end codes (the 21 + 21
+                # largest keep their exact residuals), which still leaves a score of ~80 against <= ~50 for the
+                # heaviest-tailed of the synthetic tokens: softmax mass ~1
+                pos = args.ctx // 2
+                plant_q = (torch.randn(H, HD, generator=gen, device=dev) * 3.0).half()
+                kq = rope_rotate(rope_rotate(plant_q, args.ctx + args.sinks + total), pos + args.sinks, -1.0)
+                plant = (pos, kq.reshape(-1), torch.randn(C, generator=gen, device=dev))
+            lay.fill(args.ctx, gen, dev, plant=plant)
+            caches[(s, li)] = lay
+            k, v = synth_tokens(total, lay.scale, lay.shift, gen, dev)
+            q = torch.randn(total, H, HD, generator=gen, device=dev).half()
+            qs[(s, li)], ks[(s, li)], vs[(s, li)] = q, k, v
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def stage(s, step, x):
+        for li in owned:
+            q = qs[(s, li)][step]
+            if sharded and li == owned[0]:
+                q = q + x.view(H, HD) * 1e-3          # the hand-over is a true data dependency of this stage
+            out = layer_step(caches[(s, li)], q, ks[(s, li)][step], vs[(s, li)][step])
+        return out.half().view(1, 1, C)
+
+    template = torch.zeros(1, 1, C, dtype=torch.float16, device=dev)
+    x_in = torch.zeros(1, 1, C, dtype=torch.float16, device=dev)
+    pipe = sharding.StreamPipeline(stage, streams, rank=rank, world=world if sharded else 1)
+    timers = KernelTimers()
+    timers.install()
+    pipe.run(args.warmup, lambda s, st: x_in, template, step0=0)
+    timers.reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(args.steps, lambda s, st: x_in, template, step0=args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timers.uninstall()
+    retrieval = None
+    if args.retrieval and plant_q is not None:
+        retrieval = check_retrieval(caches[(0, owned[0])], rope_rotate(plant_q, args.ctx + args.sinks + total).half(), dev)
+
+    n_tokens = args.steps * streams * (world if (world > 1 and not sharded) else 1)
+    ms_per_step = elapsed * 1000.0 / args.steps
+    value = n_tokens / elapsed
+    res = None
+    if rank == 0:
+        L_mid = args.ctx + args.warmup + args.steps // 2
+        k_us, v_us = timers.mean_us("score_k"), timers.mean_us("mix_v")
+        dom = "score_k" if (k_us or 0) >= (v_us or 0) else "mix_v"
+        dom_us = k_us if dom == "score_k" else v_us
+        dom_bytes, per_tok = algorithmic_bytes(args.bits, L_mid, dom)
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+        kb, _ = algorithmic_bytes(args.bits, L_mid, "score_k")
+        vb, _ = algorithmic_bytes(args.bits, L_mid, "mix_v")
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom, {}).get("%d_%d" % (args.bits, args.ctx), tj.get(dom, {}).get(str(args.ctx)))
+                if args.bits != 4 and ("%d_%d" % (args.bits, args.ctx)) not in tj.get(dom, {}):
+                    traffic = None
+                traffic_src = tj.get("_source")
+            except Exception:
+                traffic = None
+        if sharded:
+            par = "layer-sharded pipeline: %d ranks x %d layers, %d streams in flight, fp16 activation over RCCL p2p" \
+                  % (world, len(owned), streams)
+        elif world > 1:
+            par = "independent decode streams x%d (replicas)" % world
+        else:
+            par = "1 GPU, %d stream%s" % (streams, "s" if streams > 1 else "")
+        res = {
+            "metric": "decode tokens/s, KV-cache hot path (%d layers: NUQ append + q.K^T(RoPE)+sparse + softmax + p.V+sparse), "
+                      "LLaMA-2-7B head shape, nuq%d 1%%-sparse @%dK ctx" % (args.layers, args.bits, args.ctx // 1024),
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LLaMA-2-7B KV path: H=32 hd=128 layers=%d nuq%d + 1%% outliers (42/token), "
+                                   "ctx=%d cached tokens%s, batch 1 per stream"
+                                   % (args.layers, args.bits, args.ctx,
+                                      " + %d fp16 attention-sink tokens" % args.sinks if args.sinks else ""),
+                       "ctx": args.ctx, "bits": args.bits, "layers": args.layers, "sinks": args.sinks,
+                       "streams": streams, "parallelism": par},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
+                         "bytes_per_token": per_tok},
+            "kernels": {"score_k_us": k_us, "mix_v_us": v_us,
+                        "score_k_GBps": kb / (k_us * 1e-6) / 1e9 if k_us else None,
+                        "mix_v_GBps": vb / (v_us * 1e-6) / 1e9 if v_us else None,
+                        "kv_matvec_GBps": (kb + vb) / ((k_us + v_us) * 1e-6) / 1e9 if k_us and v_us else None,
+                        "step_GBps": len(owned) * streams * (kb + vb) / (elapsed / args.steps) / 1e9},
+            "setup_s": t_setup,
+        }
+        if label:
+            res["config"]["label"] = label
+        if retrieval is not None:
+            res["retrieval"] = retrieval
+    del caches, qs, ks, vs
+    torch.cuda.empty_cache()
+    if rank == 0 and with_baselines:
+        if not args.no_fp16_baseline:
+            fb = fp16_matvec_baseline(args.ctx, dev)
+            if fb:
+                res["fp16_baseline"] = fb
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.bits, args.cpu_sample_tokens, args.ctx, args.layers)
+    return res
 
 
 def main():
@@ -210,6 +471,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
@@ -218,92 +480,26 @@ def main():
         _lib.LIB_PATH = os.path.abspath(os.environ["KVQ_LIB"])
     _lib.lib()  # fail loudly if the HIP library is missing
 
-    total = args.steps + args.warmup
-    max_len = (args.ctx + total + 8 + 63) // 64 * 64
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    t_setup = time.time()
-    layers = []
-    for li in range(args.layers):
-        lay = Layer(args.bits, max_len, gen, dev, args.sinks)
-        lay.fill(args.ctx, gen, dev)
-        layers.append(lay)
-    # per-layer decode inputs, resident before timing
-    qs, ks, vs = [], [], []
-    for lay in layers:
-        k, v = synth_tokens(total, lay.scale, lay.shift, gen, dev)
-        q = torch.randn(total, H, HD, generator=gen, device=dev).half()
-        qs.append([q[i] for i in range(total)])
-        ks.append([k[i] for i in range(total)])
-        vs.append([v[i] for i in range(total)])
-    torch.cuda.synchronize()
-    t_setup = time.time() - t_setup
-
-    timers = KernelTimers()
-    timers.install()
-    for s in range(args.warmup):
-        decode_step(layers, qs, ks, vs, s)
-    timers.reset()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        decode_step(layers, qs, ks, vs, args.warmup + s)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    timers.uninstall()
-
-    ms_per_step = elapsed * 1000.0 / args.steps
-    value = world * args.steps / elapsed                      # decode tokens/s over all streams
-
+    if args.sweep:
+        if world > 1:
+            raise SystemExit("--sweep is a single-GPU run")
+        base = dict(vars(args))
+        # (label, ctx, bits, sinks, layers, steps): BASELINE configs 2, 3, 5 and the north-star sizes
+        cfgs = [("4K hot (1 layer, Infinity-Cache resident)", 4096, 4, 0, 1, 50),
+                ("4K rotated (32 layers)", 4096, 4, 0, 32, 20),
+                ("32K", 32768, 4, 0, 32, 20),
+                ("128K nuq3 + 5 sinks (config 3)", 131072, 3, 5, 32, 10),
+                ("32K nuq3 + 5 sinks", 32768, 3, 5, 32, 20),
+                ("1M (config 5 shape on one GPU: 8 of 32 layers, retrieval proxy)", 1048576, 4, 0, 8, 5),
+                ("1M nuq3 + 5 sinks (8 of 32 layers)", 1048576, 3, 5, 8, 5)]
+        for label, ctx, bits, sinks, layers, steps in cfgs:
+            a = argparse.Namespace(**base)
+            a.ctx, a.bits, a.sinks, a.layers, a.steps = ctx, bits, sinks, layers, steps
+            a.retrieval = ctx >= 1048576
+            r = run_config(a, rank, world, dev, dist, label=label, with_baselines=False)
+            print(json.dumps(r), flush=True)
+    res = run_config(args, rank, world, dev, dist)
     if rank == 0:
-        L_mid = args.ctx + args.warmup + args.steps // 2
-        k_us, v_us = timers.mean_us("score_k"), timers.mean_us("mix_v")
-        dom = "score_k" if (k_us or 0) >= (v_us or 0) else "mix_v"
-        dom_us = k_us if dom == "score_k" else v_us
-        dom_bytes, per_tok = algorithmic_bytes(args.bits, L_mid, dom)
-        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        kb, _ = algorithmic_bytes(args.bits, L_mid, "score_k")
-        vb, _ = algorithmic_bytes(args.bits, L_mid, "mix_v")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get(str(args.ctx))
-            except Exception:
-                traffic = None
-        res = {
-            "metric": "decode tokens/s, KV-cache hot path (32 layers: NUQ append + q.K^T(RoPE)+sparse + softmax + p.V+sparse), "
-                      "LLaMA-2-7B head shape, nuq%d 1%%-sparse @%dK ctx" % (args.bits, args.ctx // 1024),
-            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LLaMA-2-7B KV path: H=32 hd=128 layers=%d nuq%d + 1%% outliers (42/token), "
-                                   "ctx=%d cached tokens%s, batch 1 per GPU"
-                                   % (args.layers, args.bits, args.ctx,
-                                      " + %d fp16 attention-sink tokens" % args.sinks if args.sinks else ""),
-                       "ctx": args.ctx, "bits": args.bits, "layers": args.layers, "sinks": args.sinks,
-                       "parallelism": "independent decode streams x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
-                         "bytes_per_token": per_tok},
-            "kernels": {"score_k_us": k_us, "mix_v_us": v_us,
-                        "score_k_GBps": kb / (k_us * 1e-6) / 1e9 if k_us else None,
-                        "mix_v_GBps": vb / (v_us * 1e-6) / 1e9 if v_us else None,
-                        "kv_matvec_GBps": (kb + vb) / ((k_us + v_us) * 1e-6) / 1e9 if k_us and v_us else None},
-            "setup_s": t_setup,
-        }
-        if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.bits, args.cpu_sample_tokens, args.ctx, args.layers)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -610,7 +610,7 @@ void score_k_kernel(ScoreKArgs a) {
   }
 }
 
-static int workgroup_slots(int wg_per_cu) {
+static int cu_count() {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -618,7 +618,18 @@ static int workgroup_slots(int wg_per_cu) {
       n = 256;
     cus = n;
   }
-  return cus * wg_per_cu;
+  return cus;
+}
+
+// workgroups of one kernel variant that are resident at a time (registers AND LDS: the 4-wave sparse variants hold
+// 64 KB of LDS, two per CU, not the four their wave count would allow)
+template <typename K>
+static int workgroup_slots(K kernel, int threads, int fallback_per_cu) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu <= 0)
+    per_cu = fallback_per_cu;
+  (void)hipGetLastError();
+  return cu_count() * per_cu;
 }
 
 // Head groups per full tile.  A workgroup of hpg heads costs ~(hpg + 2) units (2 = the tile's trig, prologue
@@ -646,7 +657,7 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   const int64_t full_tiles = a.L / T;
   const int rem = (int)(a.L % T);
   const int max_hpg = SPARSE ? kSparseHpg : 1 << 30;
-  const int slots = workgroup_slots(16 / NWAVES);      // 128-VGPR kernels: 4 waves per SIMD
+  static const int slots = workgroup_slots(score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED>, NWAVES * 64, 16 / NWAVES);
   a.groups = full_tiles ? pick_groups(a.H, full_tiles, q_len, max_hpg, slots) : 1;
   a.hpg = a.H / a.groups;
   if (a.hpg > max_hpg) return KVQ_EINVAL;

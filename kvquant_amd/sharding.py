@@ -102,3 +102,61 @@ class LayerShardedPipeline:
                 return out
             return None
         return buf if self.rank == first else None
+
+
+class StreamPipeline:
+    """`streams` independent decode streams kept in flight through the layer-sharded stages, so that every rank
+    works on every tick: while rank r runs its layers for stream s, rank r+1 runs its layers for stream s-1
+    (classic pipeline parallelism over the reference's layer placement; with streams = 1 it degenerates to the
+    reference's sequential hand-over, which is the capacity configuration: one 1M-token stream on 8 GPUs).
+
+    stage(stream, step, x) -> y runs THIS rank's layers of `stream` for decode step `step` on activation x
+    ([1, q_len, hidden], 8 KB at decode); the hand-over between ranks is point-to-point (isend / irecv: RCCL over
+    the direct xGMI link with the nccl backend, gloo in the CPU tests), there is no collective on the data path.
+    The last rank returns each stream's final activation to rank 0 (norm / lm_head live there, ML:2583-2585);
+    rank 0 posts those receives `world - 1` items late, when the data is about to arrive, so that the last rank
+    never waits for it.
+    """
+
+    def __init__(self, stage, streams, rank=None, world=None, group=None):
+        self.stage = stage
+        self.streams = streams
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+
+    def run(self, steps, first_input, template, step0=0):
+        """first_input(stream, step) -> activation entering layer 0 (called on rank 0 only).
+        Returns on rank 0 the list of final activations in (step, stream) order, elsewhere []."""
+        W, r = self.world, self.rank
+        items = [(st, s) for st in range(step0, step0 + steps) for s in range(self.streams)]
+        if W == 1:
+            return [self.stage(s, st, first_input(s, st)) for st, s in items]
+        finals, final_reqs, sends = [], [], []
+        lag = W - 1
+
+        def post_final():
+            buf = torch.empty_like(template)
+            finals.append(buf)
+            final_reqs.append(dist.irecv(buf, src=W - 1, group=self.group))
+
+        for i, (st, s) in enumerate(items):
+            if r == 0:
+                if i >= lag:
+                    post_final()
+                x = first_input(s, st)
+            else:
+                x = torch.empty_like(template)
+                dist.recv(x, src=r - 1, group=self.group)
+            y = self.stage(s, st, x).contiguous()
+            sends.append((dist.isend(y, dst=(r + 1) % W, group=self.group), y))   # (last rank: back to rank 0)
+            if len(sends) > 2 * W + 4:      # keep a bounded number of requests (and their tensors) alive
+                sends.pop(0)[0].wait()
+        if r == 0:
+            while len(finals) < len(items):
+                post_final()
+            for q in final_reqs:
+                q.wait()
+        for q, _ in sends:
+            q.wait()
+        return finals if r == 0 else []

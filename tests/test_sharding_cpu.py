@@ -74,3 +74,47 @@ def test_pipeline_over_gloo(world, n_layers):
                 assert torch.equal(outs[step], ref)
             else:
                 assert outs[step] is None
+
+
+def _stream_worker(rank, world, port, n_layers, streams, steps, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owned = sharding.layer_assignment(n_layers, world)[rank]
+    log = []
+    # a "layer" with per-stream state (like a KV cache that grows by one token per step): order-sensitive
+    state = {(s, i): 0.0 for s in range(streams) for i in owned}
+
+    def stage(s, st, x):
+        for i in owned:
+            state[(s, i)] += 1.0
+            x = x * 1.25 + float(i) + 0.01 * state[(s, i)] + 100.0 * s
+        log.append((st, s))
+        return x
+    pipe = sharding.StreamPipeline(stage, streams)
+    x0 = torch.arange(8, dtype=torch.float32).view(1, 1, 8)
+    outs = pipe.run(steps, lambda s, st: x0 + s + 10 * st, x0)
+    ret[rank] = (log, [o.clone() for o in outs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_layers,streams", [(2, 6, 2), (3, 7, 3), (3, 6, 1), (2, 4, 5)])
+def test_stream_pipeline_over_gloo(world, n_layers, streams):
+    """real layer outputs (stateful, order-sensitive) move through the stages; every stream's result equals the
+    single-process evaluation and every rank ran every (step, stream) item exactly once, in order"""
+    steps = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_stream_worker, args=(world, _free_port(), n_layers, streams, steps, ret), nprocs=world, join=True)
+    x0 = torch.arange(8, dtype=torch.float32).view(1, 1, 8)
+    items = [(st, s) for st in range(steps) for s in range(streams)]
+    for r in range(world):
+        assert ret[r][0] == items
+    outs = ret[0][1]
+    assert len(outs) == len(items) and all(len(ret[r][1]) == 0 for r in range(1, world))
+    for k, (st, s) in enumerate(items):
+        ref = x0 + s + 10 * st
+        for i in range(n_layers):
+            ref = ref * 1.25 + float(i) + 0.01 * (st + 1) + 100.0 * s
+        assert torch.allclose(outs[k], ref, rtol=0, atol=0), (st, s)
