@@ -156,27 +156,33 @@ KVQ_API int kvq_append_k_fused(int bits, int32_t *mat, const float *lut,
                        int thr_k, int H, int hd, int64_t max_len, int64_t col,
                        float *outliers_t, int32_t *outlier_idx_t, void *stream);
 
-/* V Q-Norm (modeling_llama.py:1116-1118, 1153-1156, 1237-1240, 1369-1375), optional
- * (NULL = off) argument of the fused V appends: the second per-token codebook row
- * lut_rows2[col] = (lut_sorted*normscale + normoffset)*sf + off is written next to
- * lut_rows[col]; zp_from_rows2 != 0 makes the sparse residuals refer to
- * lut_rows2[col][zero code] instead of lut_rows[col][zero code] (the reference does so
- * at 2 bit in decode and at every width in its prefill glue). */
-typedef struct kvq_vnorm {
-  float *lut_rows2;      /* device, float [max_len][2^bits] */
+/* Options of the fused V appends (host struct, NULL = all defaults).
+ *  - Q-Norm (modeling_llama.py:1116-1118, 1153-1156, 1237-1240, 1369-1375): lut_rows2 != NULL makes the kernel write
+ *    the second per-token codebook row lut_rows2[col] = (lut_sorted*normscale + normoffset)*sf + off next to
+ *    lut_rows[col]; zp_from_rows2 != 0 makes the sparse residuals refer to lut_rows2[col][zero code] instead of
+ *    lut_rows[col][zero code] (the reference does so at 2 bit in decode and at every width in its prefill glue).
+ *  - reference_tie_quirk: the reference's V append clips an element to the zero-point code only when it lies
+ *    STRICTLY outside [22nd smallest, 22nd largest] (KCU:2084), while its glue stores the 21 largest / smallest as
+ *    sparse residuals (modeling_llama.py:1093-1096).  When the 21st and 22nd largest values are equal -- one token in
+ *    ten for fp16 activations -- that element keeps its nearest code AND gets a residual: it is counted twice
+ *    (SURVEY App. A.5).  0 (default): an element is clipped iff it is stored sparse, which is what the reference's
+ *    simulated path computes (simquant_module_quantizer.py:95-108, 347-350).  1: replicate the double count. */
+typedef struct kvq_vopts {
+  float *lut_rows2;      /* device, float [max_len][2^bits], or NULL */
   float normscale;
   float normoffset;
   int zp_from_rows2;
-} kvq_vnorm;
+  int reference_tie_quirk;
+} kvq_vopts;
 
 /* One launch = the V top-(thr_k+1) selection of modeling_llama.py:1537-1545, the
  * per-token codebook row lut_sorted*sf+off written to lut_rows[col] (1086-1114),
  * vecquant{b}appendvecVsparse, and the sparse row (1168-1176).
- * lut_sorted: float [2^bits] ascending.  norm: host pointer or NULL. */
+ * lut_sorted: float [2^bits] ascending.  opts: host pointer or NULL. */
 KVQ_API int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows,
                        const float *lut_sorted, const float *x, float *outliers,
                        int32_t *outlier_idx, int thr_k, int H, int hd,
-                       int64_t max_len, int64_t col, const kvq_vnorm *norm,
+                       int64_t max_len, int64_t col, const kvq_vopts *norm,
                        void *stream);
 
 /* Prefill forms of the two fused appends: S prompt tokens in ONE launch (one workgroup
@@ -193,7 +199,7 @@ KVQ_API int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut, const flo
 KVQ_API int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted,
                      const float *x, float *outliers, int32_t *outlier_idx, int thr_k,
                      int H, int hd, int64_t max_len, int64_t col0, int64_t S,
-                     const kvq_vnorm *norm, void *stream);
+                     const kvq_vopts *norm, void *stream);
 
 /* modeling_llama.py:873-874, 1950-1962, 1972-1977 in two launches: scores fp32
  * [H][L] (raw q.K^T) -> half -> * inv_sqrt_hd (fp16) -> softmax in fp32 over
@@ -217,7 +223,7 @@ KVQ_API int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores,
  * the two codebook values the outlier residuals refer to, contiguous -- a constant
  * of the layer that saves the selection workgroup a dependent 256 KB-strided read.
  * klut_score (optional, NULL = klut): the table the score images are built from --
- * the K Q-Norm table at 2 bit (modeling_llama.py:811-815).  vnorm: V Q-Norm or NULL. */
+ * the K Q-Norm table at 2 bit (modeling_llama.py:811-815).  vnorm: options of the V append or NULL. */
 KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
                         const float *klut_off, const void *k, const float *lo,
                         const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
@@ -226,7 +232,7 @@ KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
                         const void *q, int acts_are_half, int thr_k, int H, int hd,
                         int64_t max_len, float *koutliers_t, int32_t *kidx_t,
                         const float *klut_ends, const float *klut_score,
-                        const kvq_vnorm *vnorm, void *score_workspace,
+                        const kvq_vopts *vnorm, void *score_workspace,
                         size_t score_workspace_bytes, void *stream);
 /* kvq_score_k for q_len = 1 with the tables (and the fp32 query copy) already in
  * `workspace` (written by kvq_decode_prologue on the same stream). */

@@ -13,9 +13,9 @@ _f = ctypes.c_float
 _sz = ctypes.c_size_t
 
 class VNorm(ctypes.Structure):
-    """struct kvq_vnorm of include/kvq.h"""
+    """struct kvq_vopts of include/kvq.h"""
     _fields_ = [("lut_rows2", ctypes.c_void_p), ("normscale", ctypes.c_float), ("normoffset", ctypes.c_float),
-                ("zp_from_rows2", ctypes.c_int)]
+                ("zp_from_rows2", ctypes.c_int), ("reference_tie_quirk", ctypes.c_int)]
 
 
 _vn = ctypes.POINTER(VNorm)

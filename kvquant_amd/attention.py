@@ -49,7 +49,7 @@ class RotaryDynamic(nn.Module):
 class KVQuantAttention(nn.Module):
     def __init__(self, hidden_size=4096, num_heads=32, abits=4, include_sparse=True, first_few_fp16=0,
                  maxseqlen=4096, rope_theta=10000.0, sparsity_threshold=0.99, device=None,
-                 dtype=torch.float16, bias=False):
+                 dtype=torch.float16, bias=False, make_proj=True, use_orig_sparse=False):
         super().__init__()
         self.hidden_size = hidden_size
         self.num_heads = num_heads
@@ -57,10 +57,11 @@ class KVQuantAttention(nn.Module):
         self.first_few_fp16 = first_few_fp16
         self.rope_theta = rope_theta
         kw = dict(device=device, dtype=dtype)
-        self.q_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
-        self.k_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
-        self.v_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
-        self.o_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
+        if make_proj:     # (kvquant_amd.llama wraps a model's own projections and only uses attend())
+            self.q_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
+            self.k_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
+            self.v_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
+            self.o_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
         self.rotary_emb = RotaryDynamic(self.head_dim, base=rope_theta, device=device)
         self.kcache = QuantK(bits=abits, hidden_size=hidden_size, num_heads=num_heads,
                              max_position_embeddings=maxseqlen, include_sparse=include_sparse,

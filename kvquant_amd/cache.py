@@ -319,6 +319,11 @@ class QuantV(nn.Module):
         self.first_few_fp16 = first_few_fp16
         self.norm = False
         self.lookup_table2 = None
+        # The reference clips a value to the zero-point code only STRICTLY outside its per-token thresholds while
+        # storing the 21 largest / smallest as residuals: a selected value that EQUALS the threshold (21st == 22nd
+        # largest, ~10 % of fp16 tokens) is dequantised twice.  The GPU-resident appends clip
+        # exactly the stored values, like the reference's simulated path; True replicates the double count.
+        self.reference_tie_quirk = False
 
     @property
     def device(self):
@@ -369,8 +374,8 @@ class QuantV(nn.Module):
         sparse residuals refer to -- the Q-Norm row at 2 bit in decode (ML:1153-1156) and at every width in the
         prefill glue (ML:1369-1375).  None without Q-Norm."""
         if not self.norm:
-            return None
-        return (self.lookup_table2, self._ns, self._no, prefill or self.bits == 2)
+            return (None, 1.0, 0.0, False, True) if self.reference_tie_quirk else None
+        return (self.lookup_table2, self._ns, self._no, prefill or self.bits == 2, self.reference_tie_quirk)
 
     def mix_table(self):
         """table the p.V kernel dequantises with: the Q-Norm rows at 2 bit (ML:1237-1240)"""

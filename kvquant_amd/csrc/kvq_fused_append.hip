@@ -139,6 +139,7 @@ struct AppendArgs {
   float *lut_rows2;        // V Q-Norm (optional): [max_len][N], row `col` = (lut_sorted*normscale+normoffset)*sf+off
   float normscale, normoffset;
   int zp_from_rows2;       // V Q-Norm: the residuals refer to lut_rows2[col][zero code] (ML:1153-1156, 1369-1375)
+  int tie_quirk;           // V: replicate the reference's double count of an outlier that equals the clip threshold
   const void *x;           // element of channel c: x[c * x_stride] (fp32 or fp16); decode: [C], stride 1
   int x_is_half;
   int64_t x_stride;        // prefill pack: channel-major [C][S] input, stride S, x points at the token's column
@@ -299,7 +300,10 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
       float row[N];
 #pragma unroll
       for (int v = 0; v < N; v++) row[v] = vrow[v];
-      sh.codes[c0 + e] = (xv[e] < vmin || xv[e] > vmax) ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, xv[e]);
+      // clipped to the zero-point code iff stored sparse (include/kvq.h: kvq_vopts); with the reference's quirk:
+      // iff strictly outside the thresholds (KCU:2084), which misses a selected element that equals one of them
+      const bool clip = A.tie_quirk ? (xv[e] < vmin || xv[e] > vmax) : (in_hi[e] || in_lo[e]);
+      sh.codes[c0 + e] = clip ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, xv[e]);
     }
   }
 
@@ -467,6 +471,7 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
   a.normscale = 1.f;
   a.normoffset = 0.f;
   a.zp_from_rows2 = 0;
+  a.tie_quirk = 0;
   a.x = x;
   a.x_is_half = x_is_half;
   a.lo = lo;
@@ -482,16 +487,19 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
 
 static AppendArgs v_args(int32_t *mat, float *lut_rows, const float *lut_sorted, const void *x, int x_is_half,
                          float *outliers, int32_t *idx, int thr_k, int H, int hd, int64_t max_len, int64_t col,
-                         const kvq_vnorm *norm) {
+                         const kvq_vopts *norm) {
   AppendArgs a = k_args(mat, nullptr, nullptr, x, x_is_half, nullptr, nullptr, outliers, idx, thr_k, H, hd, max_len,
                         col);
   a.lut_rows = lut_rows;
   a.lut_sorted = lut_sorted;
-  if (norm != nullptr && norm->lut_rows2 != nullptr) {
-    a.lut_rows2 = norm->lut_rows2;
-    a.normscale = norm->normscale;
-    a.normoffset = norm->normoffset;
-    a.zp_from_rows2 = norm->zp_from_rows2;
+  if (norm != nullptr) {
+    a.tie_quirk = norm->reference_tie_quirk;
+    if (norm->lut_rows2 != nullptr) {
+      a.lut_rows2 = norm->lut_rows2;
+      a.normscale = norm->normscale;
+      a.normoffset = norm->normoffset;
+      a.zp_from_rows2 = norm->zp_from_rows2;
+    }
   }
   return a;
 }
@@ -512,7 +520,7 @@ int kvq_append_k_fused(int bits, int32_t *mat, const float *lut, const float *lu
 
 int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
                        float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
-                       int64_t col, const kvq_vnorm *norm, void *stream) {
+                       int64_t col, const kvq_vopts *norm, void *stream) {
   return launch_fused<true>(bits, v_args(mat, lut_rows, lut_sorted, x, 0, outliers, outlier_idx, thr_k, H, hd,
                                          max_len, col, norm), H, hd, (hipStream_t)stream);
 }
@@ -551,7 +559,7 @@ int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_
 
 int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,
                      float *outliers, int32_t *outlier_idx, int thr_k, int H, int hd, int64_t max_len,
-                     int64_t col0, int64_t S, const kvq_vnorm *norm, void *stream) {
+                     int64_t col0, int64_t S, const kvq_vopts *norm, void *stream) {
   return launch_pack(true, bits, v_args(mat, lut_rows, lut_sorted, x, 0, outliers, outlier_idx, thr_k, H, hd,
                                         max_len, col0, norm), H, hd, S, (hipStream_t)stream);
 }
@@ -561,7 +569,7 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
                         int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
                         float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
                         int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
-                        const float *klut_ends, const float *klut_score, const kvq_vnorm *vnorm,
+                        const float *klut_ends, const float *klut_score, const kvq_vopts *vnorm,
                         void *score_workspace, size_t score_workspace_bytes, void *stream) {
   if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
   if (score_workspace_bytes < kvq_score_k_workspace_bytes(bits, 1, H) ||

@@ -203,11 +203,13 @@ def append_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices
 
 
 def _vnorm(norm):
-    """norm: None or (lut_rows2 f32 [max_len, 2^bits], normscale, normoffset, zp_from_rows2) -> kvq_vnorm* / None"""
+    """norm: None or (lut_rows2 f32 [max_len, 2^bits] or None, normscale, normoffset, zp_from_rows2,
+    reference_tie_quirk) -> kvq_vopts* / None"""
     if norm is None:
         return None
-    rows2, ns, no, zp2 = norm
-    return ctypes.byref(_lib.VNorm(_f(rows2, "lookup_table2"), float(ns), float(no), 1 if zp2 else 0))
+    rows2, ns, no, zp2, quirk = norm
+    return ctypes.byref(_lib.VNorm(None if rows2 is None else _f(rows2, "lookup_table2"), float(ns), float(no),
+                                   1 if zp2 else 0, 1 if quirk else 0))
 
 
 def append_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, thr_k, col, norm=None):

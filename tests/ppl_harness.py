@@ -1,0 +1,162 @@
+"""BASELINE config 1 as an executable harness: the reference's SIMULATED-quantisation path
+(quant/llama_simquant.py evaluates a model whose k_proj / v_proj outputs are fake-quantised by QuantLinearSim,
+SQ:563-795) against the KERNEL path (kvquant_amd.llama: packed cache + HIP kernels) on the SAME random-init Llama,
+tokens and quantizers, compared by perplexity.  Real LLaMA-2-7B weights / wikitext-2 are not available offline, so
+the model is a seeded random-init Llama with the 7B head shape (32 heads x 128) and a reduced depth, the tokens are
+seeded random ids, and the quantizers are calibrated on the model's own activations (kvquant_amd.calibrate).
+
+TEST INFRASTRUCTURE (imports the oracle); used by tests/test_llama_gpu.py and tools/ppl_delta.py.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+
+def make_model(layers=2, vocab=32000, hidden=4096, heads=32, inter=2048, seed=0, device="cuda", maxseqlen=4096, **knobs):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvquant_amd import llama as kl
+    cfg = LlamaConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                      num_attention_heads=heads, num_key_value_heads=heads, max_position_embeddings=maxseqlen,
+                      attention_bias=False, tie_word_embeddings=False)
+    cfg = kl.kvquant_config(cfg, maxseqlen=maxseqlen, **knobs)
+    torch.manual_seed(seed)
+    model = LlamaForCausalLM(cfg).half().to(device).eval()
+    return model
+
+
+class FakeQuantLinear(nn.Module):
+    """QuantLinearSim.forward (SQ:700-795) around an existing Linear: y = fake_quant(half(x) @ W), per-channel
+    static (K) or per-token dynamic (V)."""
+
+    def __init__(self, lin, quantizer, bits, is_k, sparsity_threshold, first_few_fp16, norm):
+        super().__init__()
+        self.lin, self.q, self.bits, self.is_k = lin, quantizer, bits, is_k
+        self.thr, self.ff, self.norm = sparsity_threshold, first_few_fp16, norm
+
+    def forward(self, x):
+        from oracle import simquant as sq
+        y = self.lin(x.half())
+        shape = y.shape
+        y2 = y.reshape(-1, shape[-1]).float()
+        if self.is_k:
+            out = sq.fake_quant_k(y2, self.q, self.bits, include_sparse=True, cap_outliers=21, first_few_fp16=self.ff,
+                                  norm=self.norm)
+        else:
+            out = sq.fake_quant_v(y2, self.q, self.bits, include_sparse=True, sparsity_threshold=self.thr,
+                                  first_few_fp16=self.ff, norm=self.norm)
+        return out.reshape(shape)
+
+
+@torch.no_grad()
+def ppl_full_sequence(model, ids):
+    """next-token perplexity of one full-sequence forward (what llama_simquant.py's llama_eval computes per sample)"""
+    logits = model(ids, use_cache=False).logits[0, :-1].float()
+    return float(torch.exp(nn.functional.cross_entropy(logits, ids[0, 1:])))
+
+
+@torch.no_grad()
+def sim_path_ppl(model, ids, quantizers, bits, sparsity_threshold=0.99, first_few_fp16=-1, norm=False):
+    """the reference's simulated path: fake-quantised k_proj / v_proj outputs, stock attention"""
+    m = copy.deepcopy(model)
+    for i, layer in enumerate(m.model.layers):
+        at = layer.self_attn
+        at.k_proj = FakeQuantLinear(at.k_proj, quantizers["model.layers.%d.self_attn.k_proj" % i], bits, True,
+                                    sparsity_threshold, first_few_fp16, norm)
+        at.v_proj = FakeQuantLinear(at.v_proj, quantizers["model.layers.%d.self_attn.v_proj" % i], bits, False,
+                                    sparsity_threshold, first_few_fp16, norm)
+    return ppl_full_sequence(m, ids)
+
+
+def _deploy_arith_forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None,
+                          **kwargs):
+    """full-sequence attention over fake-quantised K / V in the DEPLOYMENT path's dtype order (ML:873-874,
+    1948-1995): RoPE on the dequantised keys in fp32 with fl32(theta_j * pos) angles, fp32 q.K^T -> half -> / sqrt(d)
+    in fp16 -> fp32 softmax -> half probabilities -> fp32 p.V -> half.  Plain torch, no kernels."""
+    import math
+    from kvquant_amd import ops
+    bsz, T, _ = hidden_states.shape
+    H, hd = self.kvq_heads, self.kvq_hd
+    dev = hidden_states.device
+    q = self.q_proj(hidden_states).view(T, H, hd).transpose(0, 1).half()
+    k = self.k_proj(hidden_states).view(T, H, hd).transpose(0, 1).float()        # fake-quantised already
+    v = self.v_proj(hidden_states).view(T, H, hd).transpose(0, 1).float()
+    th = ops.rope_freqs(self.kvq_theta, dev)                                     # theta_j as the kernels evaluate them
+    pos = torch.arange(T, device=dev, dtype=torch.float32)
+    ang = (th.unsqueeze(0) * pos.unsqueeze(1))                                   # fl32(theta * pos)
+    cos, sin = torch.cat((ang.cos(), ang.cos()), -1), torch.cat((ang.sin(), ang.sin()), -1)
+
+    def rope(x):
+        rot = torch.cat((-x[..., hd // 2:], x[..., :hd // 2]), dim=-1)
+        return x * cos + rot * sin
+    # the query is rotated in the activation dtype with fp16 cos / sin tables (attention.py: RotaryDynamic), the keys in fp32
+    inv = 1.0 / (self.kvq_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float().to(dev) / hd))
+    fr = torch.outer(pos, inv)
+    emb = torch.cat((fr, fr), dim=-1)
+    c16, s16 = emb.cos().half(), emb.sin().half()
+    qr = q * c16 + torch.cat((-q[..., hd // 2:], q[..., :hd // 2]), dim=-1) * s16
+    kr = rope(k)
+    ff = self.kvq_ff
+    if ff > 0:      # fp16 sink tokens: post-RoPE keys in fp16 (ML:1464-1466)
+        kh = self.k_proj.lin(hidden_states.half()).view(T, H, hd).transpose(0, 1)
+        khr = kh * c16 + torch.cat((-kh[..., hd // 2:], kh[..., :hd // 2]), dim=-1) * s16
+        kr[:, :ff] = khr[:, :ff].float()
+    scores = torch.matmul(qr.float(), kr.transpose(1, 2))                        # [H, T, T] fp32
+    w = (scores.half().float() * (1.0 / math.sqrt(hd))).half().float()
+    mask = torch.ones(T, T, device=dev, dtype=torch.bool).tril()
+    w = w.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(w, dim=-1, dtype=torch.float32).half().float()
+    out = torch.matmul(p, v).half()                                              # [H, T, hd]
+    out = out.transpose(0, 1).reshape(1, T, H * hd)
+    return self.o_proj(out.to(hidden_states.dtype)), None
+
+
+@torch.no_grad()
+def sim_deploy_arith_ppl(model, ids, quantizers, bits, sparsity_threshold=0.99, first_few_fp16=-1, norm=False):
+    """simulated quantisation of K / V (the reference's functions) + the deployment path's attention arithmetic"""
+    import types
+    m = copy.deepcopy(model)
+    cfg = m.config
+    theta = getattr(cfg, "rope_theta", None) or (getattr(cfg, "rope_parameters", None) or {}).get("rope_theta", 10000.0)
+    for i, layer in enumerate(m.model.layers):
+        at = layer.self_attn
+        at.k_proj = FakeQuantLinear(at.k_proj, quantizers["model.layers.%d.self_attn.k_proj" % i], bits, True,
+                                    sparsity_threshold, first_few_fp16, norm)
+        at.v_proj = FakeQuantLinear(at.v_proj, quantizers["model.layers.%d.self_attn.v_proj" % i], bits, False,
+                                    sparsity_threshold, first_few_fp16, norm)
+        at.kvq_heads, at.kvq_hd, at.kvq_theta = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads, float(theta)
+        at.kvq_ff = max(first_few_fp16, 0)
+        at.forward = types.MethodType(_deploy_arith_forward, at)
+    return ppl_full_sequence(m, ids)
+
+
+@torch.no_grad()
+def kernel_path_ppl(model, ids, quantizers, sparsity_threshold=0.99, norm=False, n_prompt=0):
+    """the deployment path: patched attention over the packed cache; token by token (deployment/llama.py --check) or,
+    with n_prompt > 0, a parallel prefill of the prompt followed by token-by-token decode"""
+    from kvquant_amd import llama as kl
+    m = copy.deepcopy(model)
+    kl.patch_llama(m, sparsity_threshold=sparsity_threshold)
+    kl.load_quantizers(m, quantizers, include_sparse=True, sparsity_threshold=sparsity_threshold, norm=norm)
+    if n_prompt:
+        return kl.prefill_then_decode(m, ids, n_prompt)["ppl"]
+    return kl.benchmark(m, ids, check=True)["ppl"]
+
+
+def run(layers=2, n_tokens=512, bits=4, first_few_fp16=0, vocab=32000, seed=0, n_prompt=0, norm=False, device="cuda"):
+    from kvquant_amd import calibrate
+    model = make_model(layers=layers, vocab=vocab, seed=seed, device=device, maxseqlen=n_tokens + 64, abits=bits,
+                       include_sparse=True, first_few_fp16=first_few_fp16)
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, vocab, (1, n_tokens), generator=g).to(device)
+    calib = torch.randint(0, vocab, (1, 2048), generator=g).to(device)
+    quantizers = calibrate.calibrate_llama(model, calib, bits=bits, include_sparse=True, sparsity_threshold=0.99, norm=norm)
+    base = ppl_full_sequence(model, ids)
+    ff = first_few_fp16 if first_few_fp16 else -1
+    sim = sim_path_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm)
+    simd = sim_deploy_arith_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm)
+    ker = kernel_path_ppl(model, ids, quantizers, norm=norm, n_prompt=n_prompt)
+    return {"layers": layers, "tokens": n_tokens, "bits": bits, "first_few_fp16": first_few_fp16, "vocab": vocab,
+            "n_prompt": n_prompt, "norm": norm, "ppl_fp16": base, "ppl_sim": sim, "ppl_sim_deploy_arith": simd,
+            "ppl_kernel": ker, "delta": ker - sim, "rel_delta": (ker - sim) / sim,
+            "rel_delta_vs_deploy_arith": (ker - simd) / simd}

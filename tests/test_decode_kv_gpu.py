@@ -95,3 +95,56 @@ def test_k_qnorm_paths_match_oracle(bits):
     assert torch.equal(ok.kcache[:, :, :L], gk.kcache[:, :, :L].cpu())
     assert torch.equal(ok.outlier_indices[:L], gk.outlier_indices[:L].cpu())
     assert torch.equal(ok.outliers[:L].view(torch.int32), gk.outliers[:L].cpu().view(torch.int32))
+
+
+@pytest.mark.parametrize("bits", [4, 2])
+def test_v_tie_at_clip_threshold(bits):
+    """A token whose 21st and 22nd largest values are EQUAL (one fp16 token in ten).  The reference clips strictly
+    outside the thresholds (KCU:2084) but stores the 21 largest as residuals (ML:1093-1096): the tied value is counted
+    twice.  Default here: clipped iff stored (its reconstruction is exact, as in the reference's simulated path);
+    reference_tie_quirk=True reproduces the reference-structured path bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd.cache import QuantV, ZERO_CODE
+    from oracle import ckernels as ck
+    from tests import util
+    dev = torch.device("cuda:0")
+    H, HD, C = decode_check.H, decode_check.HD, decode_check.C
+    quant, _, _ = decode_check.quantizer(bits, seed=3)
+    x = util.v_tokens_no_ties(1, seed=8)[0].clone()
+    top = torch.topk(x, 23)
+    x[top.indices[20]] = x[top.indices[21]]          # 21st largest := 22nd largest
+    pair = (int(top.indices[20]), int(top.indices[21]))     # two equal values: one is selected (lowest channel), one is the threshold
+    kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=8, include_sparse=True,
+              sparsity_threshold=0.99, device=dev)
+    deq = {}
+    for name, quirk in (("fixed", False), ("quirk", True)):
+        vc = QuantV(**kw)
+        vc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        vc.reference_tie_quirk = quirk
+        p = torch.ones(H, 1, 1, device=dev)
+        vc.forward_fused_sparse(p, x.half().to(dev))                       # fused GPU-resident append
+        codes = ck.unpack_codes(bits, vc.vcache.cpu(), C, 1)[0].long()
+        d = vc.lookup_table[0].cpu()[codes]
+        d.scatter_add_(0, vc.outlier_indices[0].cpu().long(), vc.outliers[0].cpu())
+        sel = [c for c in pair if c in vc.outlier_indices[0].tolist()]
+        assert len(sel) == 1
+        deq[name] = (d, int(codes[sel[0]]), vc, sel[0])
+    xf = x.half().float()
+    tied = deq["fixed"][3]
+    assert deq["fixed"][1] == ZERO_CODE[bits] and abs(float(deq["fixed"][0][tied] - xf[tied])) < 1e-5
+    tied = deq["quirk"][3]
+    assert deq["quirk"][1] != ZERO_CODE[bits] and abs(float(deq["quirk"][0][tied] - xf[tied])) > 0.5
+    # the quirk variant equals the reference-structured path (legacy kernel + torch glue) bit for bit
+    ref = QuantV(**kw)
+    ref.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+    uv, ui, lv, li = ref.topk_inputs(xf.unsqueeze(0).to(dev))
+    ref.forward_fused_sparse(torch.ones(H, 1, 1, device=dev), x.half().to(dev), uv[0], ui[0], lv[0], li[0])
+    q = deq["quirk"][2]
+    # (which of the two equal values torch.topk calls "the 22nd" is unspecified; everything else must agree, and the
+    #  dequantised token must be identical wherever the two paths stored the same channels)
+    same = sorted(ref.outlier_indices[0].tolist()) == sorted(q.outlier_indices[0].tolist())
+    if same:
+        assert torch.equal(ref.vcache, q.vcache)
+        assert torch.equal(ref.outliers[0].view(torch.int32), q.outliers[0].view(torch.int32))
+    assert torch.equal(ref.lookup_table[0], q.lookup_table[0])
