@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void pack_parallel_kernel(
       const float rangeval = (h - l) / 2;
       const float zeropoint = (h + l) / 2;
       const float xv = x[(int64_t)c * S + t];
-      rescaled[(int64_t)c * S + t] = (xv - zeropoint) / rangeval;
+      if (rescaled != nullptr) rescaled[(int64_t)c * S + t] = (xv - zeropoint) / rangeval;   // (null: codes only)
       cd[i] = nearest_code<N>(row, xv);
     }
   } else {
@@ -138,7 +138,6 @@ static int launch_pack(int bits, int32_t *mat, const float *lut, const float *x,
   if (!mat || !lut || !x || !lo || !hi || H <= 0 || hd <= 0 || hd % 32 || S < 0 || col0 < 0 ||
       col0 + S > max_len)
     return KVQ_EINVAL;
-  if (IS_K && !rescaled) return KVQ_EINVAL;
   if (S == 0) return KVQ_OK;
   const int C = H * hd;
   dim3 grid((unsigned)((S + 255) / 256), C / 32), block(256);
@@ -150,6 +149,14 @@ static int launch_pack(int bits, int32_t *mat, const float *lut, const float *x,
     default: return KVQ_EINVAL;
   }
   return check_launch();
+}
+
+// codes + pack of S prompt tokens of K without the rescaled output (the fused prefill pack selects the outliers in
+// its own kernel and leaves the per-channel codebook search to this streaming one: lane per token, the channel's
+// codebook row wave-uniform in SGPRs, i.e. read once per 256 tokens instead of once per token)
+int pack_k_codes(int bits, int32_t *mat, const float *lut, const float *x, const float *lo, const float *hi, int H,
+                 int hd, int64_t S, int64_t max_len, int64_t col0, hipStream_t st) {
+  return launch_pack<true>(bits, mat, lut, x, nullptr, lo, hi, H, hd, S, max_len, col0, st);
 }
 
 }  // namespace kvq
@@ -186,6 +193,7 @@ int kvq_append_v_sparse(int bits, int32_t *mat, const float *lut_rows, const flo
 int kvq_pack_k_sparse_parallel(int bits, int32_t *mat, const float *lut, const float *x, float *rescaled,
                                const float *lo, const float *hi, int H, int hd, int64_t S, int64_t max_len,
                                int64_t col0, void *stream) {
+  if (!rescaled) return KVQ_EINVAL;
   return launch_pack<true>(bits, mat, lut, x, rescaled, lo, hi, H, hd, S, max_len, col0, (hipStream_t)stream);
 }
 

@@ -25,16 +25,18 @@ __device__ __forceinline__ uint32_t fkey(float x) {  // ascending order-preservi
   return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
 }
 
+template <int NT, int E>
 struct SelShared {
   uint32_t hist[2][256];
-  uint32_t wsum[kSelWaves + 1];
+  uint32_t wsum[NT / 64 + 1];
   uint32_t prefix[2];
   uint32_t krem[2];
-  uint32_t scan[kSelWaves];
-  unsigned codes[kMaxPerLane * kSelThreads];
+  uint32_t scan[NT / 64];
+  unsigned codes[E * NT];
 };
 
 // exclusive block scan of one uint per lane (wave shuffles + LDS across waves)
+template <int NT>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, uint32_t &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
@@ -48,7 +50,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, ui
   __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kSelWaves; w++) {
+  for (int w = 0; w < NT / 64; w++) {
     const uint32_t s = ws[w];
     if (w < wave) base += s;
     tot += s;
@@ -60,9 +62,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, ui
 // Exact k-th order statistics of both tails of keys[0..n) (n per lane valid):
 //   T[0] = key of the k-th LARGEST element, gt[0] = #keys > T[0]
 //   T[1] = key of the k-th SMALLEST element, gt[1] = #keys < T[1]
-template <int E>
+template <int NT, int E>
 __device__ __forceinline__ void radix_select_both(const uint32_t (&key)[E], const bool (&ok)[E], uint32_t k,
-                                                  SelShared &sh, uint32_t (&T)[2], uint32_t (&gt)[2]) {
+                                                  SelShared<NT, E> &sh, uint32_t (&T)[2], uint32_t (&gt)[2]) {
   const int tid = threadIdx.x;
   if (tid < 2) {
     sh.prefix[tid] = 0;
@@ -158,8 +160,10 @@ struct AppendArgs {
 };
 
 // K: rescaled selection, per-channel LUT; V: raw selection, per-token LUT row built here.
-// Executed by one whole workgroup of kSelThreads lanes.
-template <int BITS, bool IS_V>
+// Executed by one whole workgroup of NT lanes (NT = 1024: the decode append, one latency-critical workgroup;
+// NT = 256: the prefill pack, where four times as many tokens in flight per CU hide the select's barriers),
+// E = channels per lane the arrays are sized for (C <= E * NT).
+template <int BITS, bool IS_V, int NT = kSelThreads, int E = kMaxPerLane>
 __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   uint32_t *__restrict__ mat = A.mat;
   const float *__restrict__ lut = A.lut;
@@ -173,11 +177,10 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   const int thr_k = A.thr_k, C = A.C;
   const int64_t max_len = A.max_len, col = A.col;
   constexpr int N = Fmt<BITS>::kN;
-  constexpr int E = kMaxPerLane;
-  __shared__ SelShared sh;
+  __shared__ SelShared<NT, E> sh;
   __shared__ float vrow[16], vrow2[16];
   const int tid = threadIdx.x;
-  const int per = (C + kSelThreads - 1) / kSelThreads;   // channels per lane (4 at C = 4096), <= E
+  const int per = (C + NT - 1) / NT;   // channels per lane (4 at C = 4096 / 1024 lanes), <= E
   const int c0 = tid * per;
 
   float xv[E], sel[E];
@@ -239,7 +242,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
 
   uint32_t T[2], gt[2];
   const uint32_t ksel = IS_V ? (uint32_t)(thr_k + 1) : (uint32_t)thr_k;   // V: threshold is the (thr_k+1)-th
-  radix_select_both<E>(key, ok, ksel, sh, T, gt);
+  radix_select_both<NT, E>(key, ok, ksel, sh, T, gt);
 
   // ---- membership: strictly beyond the threshold, plus the first ties in channel order ----------
   // K keeps k = thr_k per side; V keeps the top thr_k of the thr_k+1 selected (the last-ranked one,
@@ -252,7 +255,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
     ntie_lo += key[e] == T[1];
   }
   uint32_t tot;
-  const uint32_t packed = block_excl_scan(ntie_hi | (ntie_lo << 16), sh.scan, tot);
+  const uint32_t packed = block_excl_scan<NT>(ntie_hi | (ntie_lo << 16), sh.scan, tot);
   uint32_t rank_hi = packed & 0xffffu, rank_lo = packed >> 16;
   const uint32_t want_hi = (uint32_t)thr_k - gt[0], want_lo = (uint32_t)thr_k - gt[1];
   bool in_hi[E], in_lo[E];
@@ -309,7 +312,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
 
   // ---- outlier row: compaction in channel order ------------------------------------------------------
   uint32_t tot2;
-  uint32_t pos = block_excl_scan(nsel, sh.scan, tot2);   // (the barriers inside also publish sh.codes)
+  uint32_t pos = block_excl_scan<NT>(nsel, sh.scan, tot2);   // (the barriers inside also publish sh.codes)
   const int n_out = 2 * thr_k;
   float *orow = outliers + col * n_out;
   int32_t *irow = outlier_idx + col * n_out;
@@ -342,7 +345,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
 
   // ---- pack: one lane per 32-channel group ------------------------------------------------------------
   if (!own_codes) return;
-  for (int g = tid; g < C / 32; g += kSelThreads) {
+  for (int g = tid; g < C / 32; g += NT) {
     unsigned cd[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) cd[i] = sh.codes[g * 32 + i];
@@ -362,12 +365,22 @@ __global__ __launch_bounds__(kSelThreads) void fused_append_kernel(AppendArgs A)
 // elementwise launches around its pack kernel, modeling_llama.py:879-972 / 1294-1382).  The prompt arrives
 // channel-major [C][S] (KCPP:48-53): token s reads a column, 4-byte elements S apart -- the 64-byte sectors
 // are shared by 16 neighbouring tokens and come out of L2 / the Infinity Cache for all but the first.
-template <int BITS, bool IS_V>
-__global__ __launch_bounds__(kSelThreads) void fused_pack_kernel(AppendArgs A) {
-  const int64_t s = blockIdx.x;
+// kPackThreads lanes per token: 16 channels per lane at C = 4096.  Tokens are handed to the XCDs in contiguous
+// ranges (workgroup b runs on XCD b % 8, MI355X_MICROARCH.md): the 32 tokens that share each 128-byte line of the
+// channel-major input are then read through ONE L2, by workgroups that are dispatched back to back.
+constexpr int kPackThreads = 256;
+constexpr int kPackPerLane = 16;
+
+template <int BITS, bool IS_V, int NT, int E>
+__global__ __launch_bounds__(NT) void fused_pack_kernel(AppendArgs A, int64_t S) {
+  const int64_t nb = gridDim.x;
+  const int64_t per_xcd = (nb + 7) / 8;
+  int64_t s = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (nb < 64) s = blockIdx.x;
+  if (s >= S) return;
   A.col += s;
   A.x = reinterpret_cast<const float *>(A.x) + s;   // (fp32 prompt)
-  fused_append_body<BITS, IS_V>(A);
+  fused_append_body<BITS, IS_V, NT, E>(A);
 }
 
 // Decode prologue of one layer in ONE launch: workgroup 0 = K fused append, 1 = V fused append,
@@ -504,6 +517,37 @@ static AppendArgs v_args(int32_t *mat, float *lut_rows, const float *lut_sorted,
   return a;
 }
 
+template <int NT, int E>
+static int launch_pack_nt(bool is_v, int bits, const AppendArgs &a, int64_t S, hipStream_t st) {
+  const int64_t nb = S < 64 ? S : (S + 7) / 8 * 8;     // (a multiple of 8: whole XCD ranges)
+  dim3 grid((unsigned)nb), block(NT);
+  if (is_v) {
+    switch (bits) {
+      case 4: fused_pack_kernel<4, true, NT, E><<<grid, block, 0, st>>>(a, S); break;
+      case 3: fused_pack_kernel<3, true, NT, E><<<grid, block, 0, st>>>(a, S); break;
+      case 2: fused_pack_kernel<2, true, NT, E><<<grid, block, 0, st>>>(a, S); break;
+      default: return KVQ_EINVAL;
+    }
+  } else {
+    switch (bits) {
+      case 4: fused_pack_kernel<4, false, NT, E><<<grid, block, 0, st>>>(a, S); break;
+      case 3: fused_pack_kernel<3, false, NT, E><<<grid, block, 0, st>>>(a, S); break;
+      case 2: fused_pack_kernel<2, false, NT, E><<<grid, block, 0, st>>>(a, S); break;
+      default: return KVQ_EINVAL;
+    }
+  }
+  return check_launch();
+}
+
+static int launch_pack(bool is_v, int bits, AppendArgs a, int H, int hd, int64_t S, hipStream_t st) {
+  if (S <= 0 || a.col + S > a.max_len) return KVQ_EINVAL;
+  int rc = check_append(is_v, a, H, hd);
+  if (rc) return rc;
+  a.x_stride = S;
+  if (a.C <= kPackThreads * kPackPerLane) return launch_pack_nt<kPackThreads, kPackPerLane>(is_v, bits, a, S, st);
+  return launch_pack_nt<kSelThreads, kMaxPerLane>(is_v, bits, a, S, st);
+}
+
 }  // namespace kvq
 
 using namespace kvq;
@@ -525,36 +569,18 @@ int kvq_append_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut
                                          max_len, col, norm), H, hd, (hipStream_t)stream);
 }
 
-static int launch_pack(bool is_v, int bits, AppendArgs a, int H, int hd, int64_t S, hipStream_t st) {
-  if (S <= 0 || a.col + S > a.max_len) return KVQ_EINVAL;
-  int rc = check_append(is_v, a, H, hd);
-  if (rc) return rc;
-  a.x_stride = S;
-  dim3 grid((unsigned)S), block(kSelThreads);
-  if (is_v) {
-    switch (bits) {
-      case 4: fused_pack_kernel<4, true><<<grid, block, 0, st>>>(a); break;
-      case 3: fused_pack_kernel<3, true><<<grid, block, 0, st>>>(a); break;
-      case 2: fused_pack_kernel<2, true><<<grid, block, 0, st>>>(a); break;
-      default: return KVQ_EINVAL;
-    }
-  } else {
-    switch (bits) {
-      case 4: fused_pack_kernel<4, false><<<grid, block, 0, st>>>(a); break;
-      case 3: fused_pack_kernel<3, false><<<grid, block, 0, st>>>(a); break;
-      case 2: fused_pack_kernel<2, false><<<grid, block, 0, st>>>(a); break;
-      default: return KVQ_EINVAL;
-    }
-  }
-  return check_launch();
-}
-
 int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_off, const float *x,
                      const float *lo, const float *hi, float *outliers, int32_t *outlier_idx, int thr_k, int H,
                      int hd, int64_t max_len, int64_t col0, int64_t S, float *outliers_t, int32_t *outlier_idx_t,
                      void *stream) {
-  return launch_pack(false, bits, k_args(mat, lut, lut_off, x, 0, lo, hi, outliers, outlier_idx, thr_k, H, hd,
-                                         max_len, col0, outliers_t, outlier_idx_t), H, hd, S, (hipStream_t)stream);
+  // two launches: outlier selection + rows (one workgroup per token, no codebook traffic) and the streaming
+  // codes + pack kernel (codebook rows amortised over 256 tokens): 0.57 -> see DESIGN.md ms at S = 8192
+  AppendArgs a = k_args(mat, lut, lut_off, x, 0, lo, hi, outliers, outlier_idx, thr_k, H, hd, max_len, col0,
+                        outliers_t, outlier_idx_t);
+  a.codes_elsewhere = 1;
+  int rc = launch_pack(false, bits, a, H, hd, S, (hipStream_t)stream);
+  if (rc) return rc;
+  return pack_k_codes(bits, mat, lut, x, lo, hi, H, hd, S, max_len, col0, (hipStream_t)stream);
 }
 
 int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_sorted, const float *x,

@@ -18,4 +18,8 @@ inline int check_launch() {
   return KVQ_OK;
 }
 
+// kvq_append.hip: packed codes of S prompt tokens of K (no rescaled output)
+int pack_k_codes(int bits, int32_t *mat, const float *lut, const float *x, const float *lo, const float *hi, int H,
+                 int hd, int64_t S, int64_t max_len, int64_t col0, hipStream_t st);
+
 }  // namespace kvq
