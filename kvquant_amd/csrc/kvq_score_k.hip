@@ -46,6 +46,12 @@
 #ifndef KVQ_ABL
 #define KVQ_ABL 0      // ablation builds (tools/abl): timing experiments, results are wrong by construction
 #endif
+#ifndef KVQ_K_PF3
+#define KVQ_K_PF3 0            // with KVQ_K_SPARSE_AFTER: two heads of look-ahead in the mirror variant
+#endif
+#ifndef KVQ_K_SPARSE_AFTER
+#define KVQ_K_SPARSE_AFTER 0   // mirror variant: the outlier entries in batches after the head loop instead of one per head iteration
+#endif
 #ifndef KVQ_TRACE
 #define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the head loop (tools/dbg/trace_k.py)
 #endif
@@ -140,7 +146,10 @@ void score_k_kernel(ScoreKArgs a) {
   // look-ahead depth in heads: words and table of head hh+PF-1 are requested at the top of head hh.  The
   // kernel is bound by bytes in flight (Little's law at ~2 us loaded HBM latency), not by issue: the dense
   // variant has the registers and the LDS for two heads of look-ahead, the sparse one for one.
-  constexpr int PF = SPARSE ? 2 : 3;
+  // (mirror variant with KVQ_K_PF3: the outlier entries are handled after the head loop, so q in LDS is only needed
+  //  then and takes over a table buffer: three buffers fit the same 80 KB)
+  constexpr bool LATE_Q = TRANSPOSED && KVQ_K_SPARSE_AFTER && KVQ_K_PF3;
+  constexpr int PF = (SPARSE && !LATE_Q) ? 2 : 3;
   // VMEM operations of one look-ahead step that EVERY wave issues (waves with an extra table piece wait
   // for one more than they need to)
   constexpr int STEP_OPS = 2 * BITS + TAB_DMA / NWAVES;
@@ -148,11 +157,11 @@ void score_k_kernel(ScoreKArgs a) {
   // static LDS: every table offset below is a compile-time constant that folds into ds immediates
   // q of the group's heads for the sparse phase: 16 KB.  With 4-bit tables it aliases table buffer 1, which
   // is first written (by the DMA for the second head) after the sparse phase; smaller tables leave room.
-  constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 0;
+  constexpr int QL_B = (SPARSE && !LATE_Q) ? kSparseHpg * kHeadDim * 4 : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PF * TAB_B + SC_B + QL_B + KVQ_PAD_LDS];
   unsigned char *lutq = smem;                                                    // [PF][TAB_B]
   float *sc = reinterpret_cast<float *>(smem + PF * TAB_B);                      // [T][SCS]
-  float *ql = reinterpret_cast<float *>(smem + PF * TAB_B + SC_B);               // [hpg][128]
+  float *ql = reinterpret_cast<float *>(LATE_Q ? smem : smem + PF * TAB_B + SC_B);   // [hpg][128]
   const uint32_t lds0 = lds_addr(smem);
 
   const int tid = threadIdx.x;
@@ -243,7 +252,8 @@ void score_k_kernel(ScoreKArgs a) {
   auto theta_of = [&](int j) { return __shfl(th_reg, j); };
   if constexpr (SPARSE) {
     for (int i = tid; i < T * SCS; i += NT) sc[i] = 0.f;
-    for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
+    if constexpr (!LATE_Q)
+      for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
   }
 
   // packed words (role r: channel groups r and 2+r) of PF heads rotate through PF register sets
@@ -344,7 +354,9 @@ void score_k_kernel(ScoreKArgs a) {
   // first look-ahead set: after the barrier above (its latency hides behind the trig below), checked like
   // every other asm load by tools/check_isa.py
   if constexpr (TRANSPOSED) {
+#if !KVQ_K_SPARSE_AFTER
     if (nsteps > 0) sparse_fetch_t(0, spv_all[0], spc_all[0]);
+#endif
   } else if constexpr (SPARSE) {
     if (nchunks > 0) sparse_fetch(0, spv_all[0], spc_all[0]);
   }
@@ -499,15 +511,17 @@ void score_k_kernel(ScoreKArgs a) {
       // are written out once after the last head
       if (role == 0 && wact) sc[tl * SCS + ((hh + tl) & (SCS - 1))] += res;
       __builtin_amdgcn_sched_barrier(0);   // keep the sparse chunk's temporaries out of the dense section
-      static_assert(!SPARSE || PF == 2, "the sparse look-ahead registers are a two-set ring");
+      static_assert(!SPARSE || PF == 2 || LATE_Q, "the sparse look-ahead registers are a two-set ring");
       // (when there is nothing left to fetch the set is "defined" by an empty asm instead: both paths then
       // define it in place and hipcc needs no merge copy -- which it would place inside the in-flight window)
       if constexpr (TRANSPOSED) {
+#if !KVQ_K_SPARSE_AFTER
         if (nsteps > 0) {
           if (hh + 1 < nsteps) sparse_fetch_t(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);   // waited for by the next head's
           else asm volatile("" : "=v"(spv_all[1 - (buf & 1)]), "=v"(spc_all[1 - (buf & 1)]));
           if (hh < nsteps) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);   // landed: this head's vm_wait<0>
         }
+#endif
       } else if (nchunks > 0 && !(KVQ_ABL & 16)) {
         if (hh + 1 < nchunks) sparse_fetch(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);
         else asm volatile("" : "=v"(spv_all[1 - (buf & 1)]), "=v"(spc_all[1 - (buf & 1)]));
@@ -539,12 +553,17 @@ void score_k_kernel(ScoreKArgs a) {
       asm volatile("" : "+v"(v), "+v"(cidx));   // (the values exist from here on)
       sparse_chunk(j, v, cidx);
     }
+    if constexpr (LATE_Q) {
+      __syncthreads();     // every wave is done with the table buffers: q takes over the first one
+      for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
+      __syncthreads();
+    }
     if constexpr (TRANSPOSED) {
       // entries beyond the number of heads of this workgroup (ragged-tile / small-group blocks): batches of
       // TB, so that the memory latency is paid per batch (the registers of the dense loop are free here;
       // fetch and wait are back to back, nothing can touch the destinations in between)
       constexpr int TB = 7;
-      for (int s0 = nh; s0 < nsteps; s0 += TB) {
+      for (int s0 = KVQ_K_SPARSE_AFTER ? 0 : nh; s0 < nsteps; s0 += TB) {
         float v[TB];
         int ci2[TB];
 #pragma unroll
