@@ -268,6 +268,19 @@ KVQ_API int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores,
                        uint16_t *sink_probs, int H, int64_t L, int n_sink,
                        float inv_sqrt_hd, void *stream);
 
+/* ---- prefill attention (the MFMA path of BASELINE config 4) ----------------------- */
+
+/* Causal self-attention of the S prompt tokens of one sequence, all heads, flash-style on the gfx950 matrix cores
+ * (v_mfma_f32_32x32x16_f16, fp32 accumulation, online softmax): what the reference delegates to flash-attn in its
+ * prefill branch (modeling_llama.py:1861-1874, 2013-2070).  q, k, v: fp16, already RoPE'd, element [h][s][d] at
+ * h*stride_h + s*stride_s + d (strides in elements, multiples of 8, bases 16-byte aligned; d contiguous);
+ * out: fp16, same addressing (strides multiples of 4).  head_dim must be 128.
+ * out[h][s][:] = softmax_j<=s(q[h][s].k[h][j] * softmax_scale) . v[h][j][:]. */
+KVQ_API int kvq_prefill_attention(const void *q, const void *k, const void *v, void *out, int H, int S, int hd,
+                          int64_t q_stride_h, int64_t q_stride_s, int64_t k_stride_h, int64_t k_stride_s,
+                          int64_t v_stride_h, int64_t v_stride_s, int64_t o_stride_h, int64_t o_stride_s,
+                          float softmax_scale, void *stream);
+
 /* ---- uncapped ("orig") Dense-and-Sparse variants, 4 bit only ------------------ */
 
 /* VecQuant4AppendVecKSparseOrig + ...2Orig (KCU:691-931): outlier iff x<lo || x>hi ->

@@ -11,8 +11,8 @@ ML:1408/1801).
 
 Decode is GPU-resident: 6 kernel launches for the KV path, no host
 synchronisation (the reference does two device->host round trips per layer per
-token, ML:707-714 and 1803-1820).  Prefill attention uses torch SDPA where the
-reference calls flash-attn (third-party, not on the decode path).
+token, ML:707-714 and 1803-1820).  Prefill attention is kvq_prefill_attention (MFMA
+flash kernel, csrc/kvq_prefill_attn.hip) where the reference calls flash-attn.
 """
 import math
 
@@ -104,8 +104,10 @@ class KVQuantAttention(nn.Module):
         if q_len > 1 and self.kcache.klen == 0:
             # ---- prefill (ML:1861-1927) ------------------------------------------------------------
             key_rope = (key_states * cos) + (rotate_half(key_states) * sin)
-            attn = F.scaled_dot_product_attention(query_rope, key_rope, value_states, is_causal=True)
-            attn_output = attn.transpose(1, 2).reshape(bsz, q_len, self.hidden_size).contiguous()
+            # causal attention of the prompt on the matrix cores (kvq_prefill_attention, hand-written MFMA flash
+            # kernel; the reference calls flash-attn here, ML:1869-1873); output token-major, ready for o_proj
+            attn_output = ops.prefill_attention(query_rope[0].half(), key_rope[0], value_states[0]) \
+                .view(bsz, q_len, self.hidden_size).to(query_states.dtype)
             if sinks > 0:
                 n = min(sinks, q_len)
                 self.kcache_fp16[:, :, :, :n] = key_rope[:, :, :n, :].transpose(2, 3)

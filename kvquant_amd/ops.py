@@ -438,3 +438,23 @@ def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, out
     parts = score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices,
                                      inv_sqrt_hd, n_parts, outliers_t, outlier_indices_t)
     return softmax_finish(mul[0], parts, n_parts, inv_sqrt_hd, sink_scores)
+
+
+# ---- prefill attention on the matrix cores ----------------------------------------------------------------------
+def prefill_attention(q, k, v, softmax_scale=None):
+    """causal attention of a prompt: q, k, v fp16 [H, S, 128] views (any strides with a contiguous last dimension,
+    e.g. transposes of [S, H, 128]) -> fp16 [S, H*128] (token-major, ready for o_proj)."""
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float16 and t.dim() == 3 and t.stride(2) == 1):
+            raise ValueError("%s: expected an fp16 GPU tensor [H, S, head_dim] with a contiguous last dimension" % name)
+    H, S, hd = q.shape
+    if k.shape != q.shape or v.shape != q.shape:
+        raise ValueError("q, k, v must have the same shape")
+    out = torch.empty((S, H, hd), dtype=torch.float16, device=q.device)
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / (hd ** 0.5)
+    with _Dev(q):
+        _lib.check(_L().kvq_prefill_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), H, S, hd,
+                                             q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
+                                             v.stride(1), out.stride(1), out.stride(0), scale, _stream()),
+                   "kvq_prefill_attention")
+    return out.view(S, H * hd)
