@@ -49,9 +49,6 @@
 #ifndef KVQ_V_WAVES
 #define KVQ_V_WAVES 4    // waves per SIMD the register allocation aims at
 #endif
-#ifndef KVQ_V_SPREAD
-#define KVQ_V_SPREAD 0   // 1: issue the next chunk's DMA pieces spread over the quads of the math instead of one burst after the barrier (measured: no gain, 88 vs 88 us -- the burst's queueing is hidden by the other waves)
-#endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24
 #endif
@@ -92,13 +89,20 @@ struct VCfg {
   static constexpr int LUT_B = CT * N * 4;
   static constexpr int P_B = HW * CT * 4;
   static constexpr int QPL = QR / SLOTS;               // quads per lane per chunk
-  static constexpr int BUF_B = TILE_B + LUT_B + P_B;   // one pipeline stage
+  // LDS layout of the two pipeline stages: the small arrays first, so that every look-up address of either stage is
+  // an instruction immediate (16 bits) on top of a byte-sized register value: [rows 0][rows 1][p 0][p 1][p 2][tile 0][tile 1]
+  // (p 2: the fused-softmax mode converts scores one chunk ahead of the one being read)
+  static constexpr int NPB = 3;
+  static constexpr int lut_off(int st) { return st * LUT_B; }
+  static constexpr int p_off(int st) { return 2 * LUT_B + st * P_B; }
+  static constexpr int tile_off(int st) { return 2 * LUT_B + NPB * P_B + st * TILE_B; }
+  static constexpr int STAGES_B = 2 * LUT_B + NPB * P_B + 2 * TILE_B;
   static constexpr int RED_B = NT * CHL * 4;           // slot reduction (aliases the stages)
   // sparse phase after the loop (aliases the stages): staged probabilities of the workgroup's token share
   // (37 KB: 288 tokens x 32 heads, odd row stride) + 32 KB of 64-bit accumulators (4096 channels in one pass)
   static constexpr int SP_P_B = 37888;
   static constexpr int SP_B = SP_P_B + 32768;
-  static constexpr int SMEM_0 = (2 * BUF_B > RED_B ? 2 * BUF_B : RED_B);
+  static constexpr int SMEM_0 = (STAGES_B > RED_B ? STAGES_B : RED_B);
   static constexpr int SMEM_B = KVQ_V_NOSP ? SMEM_0 : (SMEM_0 > SP_B ? SMEM_0 : SP_B);
   static_assert(QR % SLOTS == 0, "slots must split the chunk's quads");
 };
@@ -120,6 +124,16 @@ struct MixArgs {
   int n_units;
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out)
+  // FUSED softmax (decode, q_len = 1): `p` is unused; the kernel reads the RAW scores and the per-(head, tile)
+  // (max, sum) partials of the score kernel, merges them, and converts scores to probabilities on the way
+  // (exactly the arithmetic of kvq_softmax_finish: half(expf(half(half(s) * inv) - M) / Z))
+  const float *scores;     // [H][L]
+  const float *parts;      // [H][n_parts][2]
+  int n_parts;
+  float inv;
+  const __half *sink;      // [H][n_sink] fp16 scaled sink scores or null
+  __half *sink_probs;      // [H][n_sink]
+  int n_sink;
 #if KVQ_TRACE
   unsigned long long *trace;   // development: [block][wave][chunk][8]
 #endif
@@ -140,10 +154,7 @@ struct DmaLane {
 template <int BITS>
 __device__ __forceinline__ DmaLane make_dma_lane() {
   using Cfg = VCfg<BITS>;
-  int lane = threadIdx.x & 63;
-  // (recomputed where it is needed: the asm keeps hipcc from hoisting the rarely taken clamped path's lane
-  //  constants out of the chunk loop, where they would be spilled and reloaded around the DMA issue)
-  asm volatile("" : "+v"(lane));
+  const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   DmaLane d;
   const int s = wave * 64 + lane;              // slot of the wave's first tile instruction
@@ -162,14 +173,39 @@ __device__ __forceinline__ DmaLane make_dma_lane() {
   return d;
 }
 
-// issue the DMA of one chunk (tokens [c0, c0+CT)) into stage `buf`.  PART < 0: everything (the first chunk);
-// PART = q in [0, QPL): the share that is issued at the top of quad q of the previous chunk's math -- tile pieces
-// k with k % QPL == q, and with q == 0 the codebook rows and the probabilities.  Issued in one burst right after
-// the chunk barrier, the 42 pieces of the workgroup's 8 waves queue up behind each other in the CU's memory
-// front end and cost every wave ~1300 cycles per chunk (17 % of the kernel, measured with s_memtime).
-template <int BITS, int PART = -1>
-__device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, uint32_t buf, int64_t c0,
-                                            int row_base, int n_rows_valid, int h0, int b) {
+// probabilities (or, fused softmax: raw scores) of the workgroup's heads for tokens [c0, c0+CT) -> LDS `pbuf`
+// ([HW][CT] floats), 4 B per lane
+template <int BITS>
+__device__ __forceinline__ void issue_p(const float *src, const MixArgs &a, const DmaLane &d, uint32_t pbuf, int64_t c0,
+                                        int h0, int b) {
+  using Cfg = VCfg<BITS>;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int NW = Cfg::NT / 64;
+  constexpr int N_P = Cfg::P_B / 256;
+  constexpr int K_P = (N_P + NW - 1) / NW;
+  const int lim_L = (int)(a.L - c0);           // tokens from the chunk start to the end of the cache
+  const float *gbase = src + ((int64_t)b * a.H + h0) * a.L + c0;
+  const uint32_t toff = (uint32_t)(lim_L <= 0 ? 0 : ((int)d.p_tok < lim_L ? (int)d.p_tok : lim_L - 1));
+  if (lim_L <= 0) gbase = src + ((int64_t)b * a.H + h0) * a.L + a.L - 1;
+#pragma unroll
+  for (int k = 0; k < K_P; k++) {
+    const int j = wave + k * NW;
+    if (j < N_P) {
+      int hr = d.p_head + k * NW * (64 / Cfg::CT);
+      if (h0 + hr >= a.H) hr = a.H - 1 - h0;
+      const uint32_t voff = ((uint32_t)hr * (uint32_t)a.L + toff) * 4u;
+      dma4(gbase, voff, pbuf + j * 256);
+    }
+  }
+}
+
+// issue the DMA of one chunk (tokens [c0, c0+CT)) into stage `buf`.  (Issued in one burst right after the chunk
+// barrier, the 42 pieces of the workgroup's 8 waves queue up in the CU's memory front end and cost every wave ~1300
+// cycles per chunk by s_memtime -- but spreading them over the math was measured neutral, 88 vs 88 us: the queueing
+// is hidden by the other waves.)
+template <int BITS>
+__device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, uint32_t lds0, int stage, int64_t c0,
+                                            int row_base, int n_rows_valid, int h0, int b, bool with_p = true) {
   using Cfg = VCfg<BITS>;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NW = Cfg::NT / 64;
@@ -177,75 +213,60 @@ __device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, 
   constexpr int N_TILE = Cfg::TILE_B / 1024;
   constexpr int K_TILE = (N_TILE + NW - 1) / NW;     // tile instructions per wave
   constexpr int LUT_SLOTS = Cfg::LUT_B / 16;
-  constexpr int N_P = Cfg::P_B / 256;
-  constexpr int K_P = (N_P + NW - 1) / NW;
   // ---- packed rows: uniform base per instruction, ONE 32-bit lane offset (bytes) for all of them
   // (token clamps in 32-bit arithmetic relative to the chunk: wave-uniform 64-bit limits, 32-bit lane values --
   // 64-bit per-lane compares cost VGPR pairs, and a spill in here makes hipcc drain the DMAs just issued)
   const int lim_len = (int)(a.max_len - c0);   // tokens from the chunk start to the end of the rows (multiple of 4, >= 4)
-  const int lim_L = (int)(a.L - c0);           // ... to the end of the cache (>= 1)
   {
     const uint32_t *gbase = a.mat + (int64_t)row_base * a.max_len + c0;
     const int tq = (int)d.tile_q4;
     const uint32_t toff = (uint32_t)(tq + 4 > lim_len ? lim_len - 4 : tq);
 #pragma unroll
     for (int k = 0; k < K_TILE; k++) {
-      if (PART >= 0 && k % Cfg::QPL != PART) continue;
       const int j = wave + k * NW;
       if (j < N_TILE) {
         int r = d.tile_row + k * NW * RPI;
         if (r >= n_rows_valid) r = n_rows_valid - 1;
         const uint32_t voff = ((uint32_t)r * (uint32_t)a.max_len + toff) * 4u;   // < 2^32 (checked by the host)
-        dma16(gbase, voff, buf + j * 1024);
+        dma16(gbase, voff, lds0 + Cfg::tile_off(stage) + j * 1024);
       }
     }
   }
-  if (PART > 0) return;
   // ---- codebook rows of the chunk
   if ((int)threadIdx.x < LUT_SLOTS) {   // wave-granular: LUT_SLOTS is a multiple of 64 or < 64
     const int tr2 = (int)d.lut_tok < lim_len ? (int)d.lut_tok : lim_len - 1;
     const float *gbase = a.lut_rows + c0 * Cfg::N;
     const uint32_t voff = ((uint32_t)tr2 * Cfg::N + d.lut_sub) * 4u;
-    dma16(gbase, voff, buf + Cfg::TILE_B + wave * 1024);
+    dma16(gbase, voff, lds0 + Cfg::lut_off(stage) + wave * 1024);
   }
-  // ---- probabilities of the workgroup's heads, 4 B per lane
-  {
-    const float *gbase = a.p + ((int64_t)b * a.H + h0) * a.L + c0;
-    const uint32_t toff = (uint32_t)((int)d.p_tok < lim_L ? (int)d.p_tok : lim_L - 1);
-#pragma unroll
-    for (int k = 0; k < K_P; k++) {
-      const int j = wave + k * NW;
-      if (j < N_P) {
-        int hr = d.p_head + k * NW * (64 / Cfg::CT);
-        if (h0 + hr >= a.H) hr = a.H - 1 - h0;
-        const uint32_t voff = ((uint32_t)hr * (uint32_t)a.L + toff) * 4u;
-        dma4(gbase, voff, buf + Cfg::TILE_B + Cfg::LUT_B + j * 256);
-      }
-    }
-  }
+  if (with_p) issue_p<BITS>(a.p, a, d, lds0 + Cfg::p_off(stage), c0, h0, b);
 }
 
-// The common case of issue_chunk -- a chunk that lies entirely inside the rows (c0 + CT <= max_len) and inside the
-// cache (c0 + CT <= L), a full unit group -- needs no clamps: the per-lane part of every source address is a
-// constant of the kernel (three VGPRs), everything that changes with the chunk or the piece goes into the
-// wave-uniform base.  PART as above.  Keeps the register pressure of the math loop low: a spill in there makes
-// hipcc drain the DMAs just issued.
+
+// The common case of issue_chunk -- a chunk that lies entirely inside the rows and the cache, a full unit group --
+// needs no clamps: the per-lane part of every source address is a constant of the kernel (three VGPRs), everything
+// that changes with the chunk or the piece is in the wave-uniform base.  PART q in [0, QPL): the tile pieces k with
+// k % QPL == q, and with q == 0 the codebook rows and the probabilities: the hand-scheduled loop issues one part per
+// quad, between its look-ups.  (Issued in one burst after the chunk barrier, the 42 pieces of a workgroup queue up in
+// the CU's memory front end -- 64 B/clk -- and every wave sits ~1500 cycles per chunk in the issue, 20 % of the
+// kernel by s_memtime once the look-up loop itself is fast.)
 struct DmaFast {
-  uint32_t tile;   // byte offset of the lane inside every tile piece (the other two are recomputed at the issue)
+  uint32_t tile, lut, p;   // byte offsets
 };
 
 template <int BITS>
-__device__ __forceinline__ DmaFast make_dma_fast(const MixArgs &a) {
+__device__ __forceinline__ DmaFast make_dma_fast(const MixArgs &a, const DmaLane &d) {
   using Cfg = VCfg<BITS>;
-  const DmaLane d = make_dma_lane<BITS>();
   DmaFast f;
   f.tile = (d.tile_row * (uint32_t)a.max_len + d.tile_q4) * 4u;
+  f.lut = (d.lut_tok * Cfg::N + d.lut_sub) * 4u;
+  f.p = (d.p_head * (uint32_t)a.L + d.p_tok) * 4u;
   return f;
 }
 
 template <int BITS, int PART>
-__device__ __forceinline__ void issue_fast(const MixArgs &a, const DmaFast &f, uint32_t buf, int64_t c0,
-                                           int row_base, int h0, int b) {
+__device__ __forceinline__ void issue_fast(const MixArgs &a, const DmaFast &f, uint32_t lds0, int stage, int pstage,
+                                           const float *psrc, int64_t c0, int row_base, int h0, int b) {
   using Cfg = VCfg<BITS>;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NW = Cfg::NT / 64;
@@ -259,19 +280,68 @@ __device__ __forceinline__ void issue_fast(const MixArgs &a, const DmaFast &f, u
   for (int k = 0; k < K_TILE; k++) {
     if (k % Cfg::QPL != PART) continue;
     const int j = wave + k * NW;
-    if (j < N_TILE) dma16(a.mat + (int64_t)(row_base + k * NW * RPI) * a.max_len + c0, f.tile, buf + j * 1024);
+    if (j < N_TILE)
+      dma16(a.mat + (int64_t)(row_base + k * NW * RPI) * a.max_len + c0, f.tile, lds0 + Cfg::tile_off(stage) + j * 1024);
   }
   if (PART != 0) return;
-  const DmaLane d = make_dma_lane<BITS>();   // (a dozen VALU per chunk; as constants they would cost two VGPRs in the math loop)
-  const uint32_t f_lut = (d.lut_tok * Cfg::N + d.lut_sub) * 4u;
-  const uint32_t f_p = (d.p_head * (uint32_t)a.L + d.p_tok) * 4u;
-  if ((int)threadIdx.x < LUT_SLOTS) dma16(a.lut_rows + c0 * Cfg::N, f_lut, buf + Cfg::TILE_B + wave * 1024);
+  if ((int)threadIdx.x < LUT_SLOTS) dma16(a.lut_rows + c0 * Cfg::N, f.lut, lds0 + Cfg::lut_off(stage) + wave * 1024);
 #pragma unroll
   for (int k = 0; k < K_P; k++) {
     const int j = wave + k * NW;
     if (j < N_P)
-      dma4(a.p + ((int64_t)b * a.H + h0 + k * NW * (64 / Cfg::CT)) * a.L + c0, f_p, buf + Cfg::TILE_B + Cfg::LUT_B + j * 256);
+      dma4(psrc + ((int64_t)b * a.H + h0 + k * NW * (64 / Cfg::CT)) * a.L + c0, f.p, lds0 + Cfg::p_off(pstage) + j * 256);
   }
+}
+
+#ifndef KVQ_V_SPREAD
+#define KVQ_V_SPREAD 1   // hand-scheduled loop: issue the next chunk's DMA a quad's share at a time (0: one burst after the barrier)
+#endif
+#ifndef KVQ_V_ASM
+#define KVQ_V_ASM 1   // 4 bit: the chunk's look-up loop as hand-scheduled instruction groups (0: what hipcc makes of the C++)
+#endif
+
+// ---- hand-scheduled pieces of the 4-bit look-up loop ---------------------------------------------------------
+// hipcc's own schedule of the loop runs at 8.4 ns per code-step per SIMD, VALU and LDS time ADDED UP; the same
+// instructions issued as below -- the look-ups of token t+1 in flight while token t is accumulated, plain v_fmac
+// (v_pk_fma_f32 takes two passes), one prepare step per word -- run at 5.7 (tools/ubench/lut_loop.hip).
+// LDS operations return in order, so s_waitcnt lgkmcnt(N) = "all but the last N issued have landed".
+template <int OFF>
+__device__ __forceinline__ void lds_read16(uint4 &w, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16(float4 &w, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(addr), "n"(OFF) : "memory");
+}
+// nibbles of w -> bytes holding code*4 + slot*64: even nibbles in we, odd in wo
+__device__ __forceinline__ void nib_prep(uint32_t &we, uint32_t &wo, uint32_t w, uint32_t slotpat) {
+  asm volatile("v_lshlrev_b32 %0, 2, %2\n\tv_lshrrev_b32 %1, 2, %2\n\tv_and_or_b32 %0, %0, %4, %3\n\tv_and_or_b32 %1, %1, %4, %3"
+               : "=&v"(we), "=&v"(wo) : "v"(w), "v"(slotpat), "s"(0x3C3C3C3Cu));
+}
+__device__ __forceinline__ void nib_extract(uint32_t (&u)[8], uint32_t we, uint32_t wo) {
+  asm volatile("v_and_b32 %0, 0xff, %8\n\tv_and_b32 %1, 0xff, %9\n\tv_bfe_u32 %2, %8, 8, 8\n\tv_bfe_u32 %3, %9, 8, 8\n\t"
+               "v_bfe_u32 %4, %8, 16, 8\n\tv_bfe_u32 %5, %9, 16, 8\n\tv_lshrrev_b32 %6, 24, %8\n\tv_lshrrev_b32 %7, 24, %9"
+               : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+               : "v"(we), "v"(wo));
+}
+template <int OFF>
+__device__ __forceinline__ void lut_read8(float (&v)[8], const uint32_t (&u)[8]) {
+  asm volatile("ds_read_b32 %0, %8 offset:%16\n\tds_read_b32 %1, %9 offset:%16\n\tds_read_b32 %2, %10 offset:%16\n\t"
+               "ds_read_b32 %3, %11 offset:%16\n\tds_read_b32 %4, %12 offset:%16\n\tds_read_b32 %5, %13 offset:%16\n\t"
+               "ds_read_b32 %6, %14 offset:%16\n\tds_read_b32 %7, %15 offset:%16"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+               : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]), "n"(OFF)
+               : "memory");
+}
+__device__ __forceinline__ void fmac8(float (&a)[8], const float (&v)[8], float p) {
+  asm volatile("v_fmac_f32 %0, %8, %16\n\tv_fmac_f32 %1, %9, %16\n\tv_fmac_f32 %2, %10, %16\n\tv_fmac_f32 %3, %11, %16\n\t"
+               "v_fmac_f32 %4, %12, %16\n\tv_fmac_f32 %5, %13, %16\n\tv_fmac_f32 %6, %14, %16\n\tv_fmac_f32 %7, %15, %16"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(p));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int BITS, int I, int WORDS>
@@ -309,9 +379,10 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   const int n_chunks = (int)((t1 - t0 + CT - 1) / CT);
 
   const uint32_t lds0 = lds_addr(smem);
-  issue_chunk<BITS>(a, make_dma_lane<BITS>(), lds0, t0, row_base, n_rows_valid, h0, b);
-  const DmaFast df = make_dma_fast<BITS>(a);
-  // chunks whose DMA needs no clamps (see issue_fast): all that start before `fast_end`
+  const DmaLane dl = make_dma_lane<BITS>();
+  issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b);
+  const DmaFast df = make_dma_fast<BITS>(a, dl);
+  // chunks whose DMA needs no clamps (see issue_fast): all that start at or before `fast_end`
   int64_t fast_end = (a.max_len < a.L ? a.max_len : a.L) - CT;
   if (n_units_valid != Cfg::UW) fast_end = -1;
 
@@ -464,6 +535,17 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   // slot pattern OR-ed into the pre-masked nibble bytes (4-bit fast path): byte = slot*64 + code*4
   const uint32_t slotpat = (uint32_t)sl * 0x40404040u;
 
+  // 4 bit, hand-scheduled loop: the lane's LDS addresses inside a stage do not change with the chunk
+  uint32_t taddr[Cfg::QPL];   // its 16-byte quads of the tile
+  uint32_t paddr = 0;         // the probabilities of its head for its slot's tokens
+  if constexpr (BITS == 4 && KVQ_V_ASM) {
+    if (lds0 != 0) __builtin_trap();   // (the instruction immediates below assume the one static LDS array at 0)
+#pragma unroll
+    for (int qq = 0; qq < Cfg::QPL; qq++)
+      taddr[qq] = (uint32_t)(rowoff[0] + (((sl * Cfg::QPL + qq + rot[0]) & (Cfg::QR - 1)) << 4));
+    paddr = (uint32_t)((hl * CT + sl * Cfg::QPL * 4) * 4);
+  }
+
   auto chunk = [&](auto STAGE, int ci) {
     constexpr int stage = decltype(STAGE)::value;
     const int64_t c0 = t0 + (int64_t)ci * CT;
@@ -480,21 +562,20 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #if KVQ_TRACE
     stamp(1);
 #endif
-    __syncthreads();                      // ... and everybody else's; the other stage is free again
+    if (!(KVQ_V_DBG & 32)) __syncthreads();   // ... and everybody else's; the other stage is free again
 #if KVQ_TRACE
     stamp(2);
 #endif
-    const int64_t cn0 = (KVQ_V_DBG & 4) ? t0 : c0 + CT;          // start of the next chunk
-    const bool more = ci + 1 < n_chunks && !(KVQ_V_DBG & 2);
-    const bool fast = KVQ_V_SPREAD && cn0 <= fast_end;               // (wave-uniform)
-    if (more && !fast)
-      issue_chunk<BITS>(a, make_dma_lane<BITS>(), lds0 + (1 - stage) * Cfg::BUF_B, cn0, row_base, n_rows_valid, h0, b);
+    const int64_t cn0 = (KVQ_V_DBG & 4) ? t0 : c0 + CT;                   // start of the next chunk
+    const bool more = ci + 1 < n_chunks && (!(KVQ_V_DBG & 2) || a.q_len > 1000);
+    const bool spread = BITS == 4 && KVQ_V_ASM && KVQ_V_SPREAD && cn0 <= fast_end;   // (wave-uniform)
+    if (more && !spread) issue_chunk<BITS>(a, dl, lds0, 1 - stage, cn0, row_base, n_rows_valid, h0, b);
 #if KVQ_TRACE
     stamp(3);
 #endif
-    const unsigned char *tile = smem + stage * Cfg::BUF_B;
-    const unsigned char *lutb = smem + stage * Cfg::BUF_B + Cfg::TILE_B;
-    float *pb = reinterpret_cast<float *>(smem + stage * Cfg::BUF_B + Cfg::TILE_B + Cfg::LUT_B);
+    const unsigned char *tile = smem + Cfg::tile_off(stage);
+    const unsigned char *lutb = smem + Cfg::lut_off(stage);
+    float *pb = reinterpret_cast<float *>(smem + Cfg::p_off(stage));
     const int rem = (int)(t1 - c0);       // tokens of this range left in the chunk
     if (rem < CT) {                       // ragged last chunk: zero the probabilities past the end once
       for (int i = tid; i < Cfg::HW * CT; i += Cfg::NT)
@@ -502,6 +583,44 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       __syncthreads();
     }
     if (KVQ_V_DBG & 1) return;
+    if constexpr (BITS == 4 && KVQ_V_ASM) {
+      constexpr int S0 = Cfg::tile_off(stage);                  // tile
+      constexpr int L0 = Cfg::lut_off(stage);                   // codebook rows (row (qq*4+e)*SLOTS + slot)
+      constexpr int P0 = Cfg::p_off(stage);                     // probabilities
+      constexpr int TS = Cfg::SLOTS * N * 4;                    // bytes between the rows of consecutive tokens of a slot
+      uint4 wq[2];
+      float4 pq[2];
+      lds_read16<S0>(wq[0], taddr[0]);
+      lds_read16<P0>(pq[0], paddr);
+      static_for<0, Cfg::QPL>([&](auto QQ) {
+        constexpr int qq = decltype(QQ)::value;
+        constexpr int cur = qq & 1;
+        uint32_t we, wo, ua[8], ub[8];
+        float va[8], vb[8];
+        lds_wait<0>();                                          // this quad's words and probabilities
+        nib_prep(we, wo, wq[cur].x, slotpat); nib_extract(ua, we, wo); lut_read8<L0 + (qq * 4 + 0) * TS>(va, ua);
+        nib_prep(we, wo, wq[cur].y, slotpat); nib_extract(ub, we, wo); lut_read8<L0 + (qq * 4 + 1) * TS>(vb, ub);
+        // a quad's share of the next chunk's DMA, behind 16 look-ups in flight (the other stage is free since the barrier)
+        if (more && spread) issue_fast<BITS, qq>(a, df, lds0, 1 - stage, 1 - stage, a.p, cn0, row_base, h0, b);
+        lds_wait<8>(); fmac8(acc, va, pq[cur].x);
+        nib_prep(we, wo, wq[cur].z, slotpat); nib_extract(ua, we, wo); lut_read8<L0 + (qq * 4 + 2) * TS>(va, ua);
+        lds_wait<8>(); fmac8(acc, vb, pq[cur].y);
+        nib_prep(we, wo, wq[cur].w, slotpat); nib_extract(ub, we, wo); lut_read8<L0 + (qq * 4 + 3) * TS>(vb, ub);
+        if constexpr (qq + 1 < Cfg::QPL) {                      // the next quad, behind the look-ups in flight
+          lds_read16<S0>(wq[1 - cur], taddr[qq + 1]);
+          lds_read16<P0 + (qq + 1) * 16>(pq[1 - cur], paddr);
+          lds_wait<10>(); fmac8(acc, va, pq[cur].z);
+          lds_wait<2>(); fmac8(acc, vb, pq[cur].w);
+        } else {
+          lds_wait<8>(); fmac8(acc, va, pq[cur].z);
+          lds_wait<0>(); fmac8(acc, vb, pq[cur].w);
+        }
+      });
+#if KVQ_TRACE
+      stamp(4);
+#endif
+      return;
+    }
     int rotv[WORDS];
 #pragma unroll
     for (int wi = 0; wi < WORDS; wi++) {
@@ -510,14 +629,24 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     }
     static_for<0, Cfg::QPL>([&](auto QQ) {
       constexpr int qq = decltype(QQ)::value;
-      // the next chunk's DMA, a quad's share at a time (the other stage is free since the barrier above)
-      if (more && fast) issue_fast<BITS, qq>(a, df, lds0 + (1 - stage) * Cfg::BUF_B, cn0, row_base, h0, b);
       const int q = sl * Cfg::QPL + qq;
       uint4 wq[WORDS];
 #pragma unroll
-      for (int wi = 0; wi < WORDS; wi++)
-        wq[wi] = *reinterpret_cast<const uint4 *>(tile + rowoff[wi] + (((q + rotv[wi]) & (Cfg::QR - 1)) << 4));
-      const float4 p4 = *reinterpret_cast<const float4 *>(pb + hl * CT + q * 4);
+      for (int wi = 0; wi < WORDS; wi++) {
+        if (KVQ_V_DBG & 16) {
+          wq[wi] = make_uint4(rotv[wi] * 0x9E3779B1u, rowoff[wi] * 0x85EBCA6Bu, tid * 0xC2B2AE35u, (tid + q) * 0x27D4EB2Fu);
+          asm volatile("" : "+v"(wq[wi].x), "+v"(wq[wi].y), "+v"(wq[wi].z), "+v"(wq[wi].w));
+        } else {
+          wq[wi] = *reinterpret_cast<const uint4 *>(tile + rowoff[wi] + (((q + rotv[wi]) & (Cfg::QR - 1)) << 4));
+        }
+      }
+      float4 p4;
+      if (KVQ_V_DBG & 8) {
+        p4 = make_float4(0.5f, 0.25f, 0.125f, 0.0625f);
+        asm volatile("" : "+v"(p4.x), "+v"(p4.y), "+v"(p4.z), "+v"(p4.w));
+      } else {
+        p4 = *reinterpret_cast<const float4 *>(pb + hl * CT + q * 4);
+      }
       static_for<0, 4>([&](auto E) {
         constexpr int e = decltype(E)::value;
         uint32_t w[WORDS];

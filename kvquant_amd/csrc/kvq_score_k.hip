@@ -441,7 +441,7 @@ void score_k_kernel(ScoreKArgs a) {
     // accumulators: the LDS pipe needs >= 16 reads in flight per wave to run at rate, and a single
     // accumulator would serialise the FMAs
     f32x2 acc4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    if (wact) {
+    if (wact && !(KVQ_ABL & 64)) {
     if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -519,7 +519,7 @@ void score_k_kernel(ScoreKArgs a) {
         if (nsteps > 0) {
           if (hh + 1 < nsteps) sparse_fetch_t(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);   // waited for by the next head's
           else asm volatile("" : "=v"(spv_all[1 - (buf & 1)]), "=v"(spc_all[1 - (buf & 1)]));
-          if (hh < nsteps) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);   // landed: this head's vm_wait<0>
+          if (hh < nsteps && !(KVQ_ABL & 128)) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);   // landed: this head's vm_wait<0>
         }
 #endif
       } else if (nchunks > 0 && !(KVQ_ABL & 16)) {
