@@ -149,7 +149,7 @@ class KernelTimers:
 
     def install(self):
         from kvquant_amd import ops
-        self._orig = (ops.score_k_prepared_softmax, ops.mix_v)
+        self._orig = (ops.score_k_prepared_softmax, ops.mix_v, ops.mix_v_softmax)
         pairs = self.pairs
 
         def wrap(fn, key):
@@ -164,10 +164,11 @@ class KernelTimers:
             return inner
         ops.score_k_prepared_softmax = wrap(ops.score_k_prepared_softmax, "score_k")   # (+ fused softmax pass 1)
         ops.mix_v = wrap(ops.mix_v, "mix_v")
+        ops.mix_v_softmax = wrap(ops.mix_v_softmax, "mix_v")             # (+ second softmax pass, + slab reduce)
 
     def uninstall(self):
         from kvquant_amd import ops
-        ops.score_k_prepared_softmax, ops.mix_v = self._orig
+        ops.score_k_prepared_softmax, ops.mix_v, ops.mix_v_softmax = self._orig
 
     def reset(self):
         for k in self.pairs:

@@ -268,6 +268,22 @@ KVQ_API int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores,
                        uint16_t *sink_probs, int H, int64_t L, int n_sink,
                        float inv_sqrt_hd, void *stream);
 
+/* kvq_softmax_finish + kvq_mix_v (q_len = 1) in ONE streaming pass: the p.V kernel
+ * merges the (max, sum) partials itself and turns raw scores into the fp16-rounded
+ * probabilities in LDS, a chunk ahead of its look-up loop -- the [H][L] probabilities
+ * of modeling_llama.py:1976 never exist in memory (one launch, 13 us and 8 bytes per
+ * token and head less at 128K).  Same arithmetic per element as kvq_softmax_finish;
+ * the row normaliser is merged in a different order (last-bit differences).  Shapes
+ * the streaming kernel does not take (max_len % 4 != 0, H > 128) run the two passes
+ * separately through `probs` (float [H][L] scratch; may be NULL otherwise).
+ * workspace: kvq_mix_v_workspace_bytes(bits, 1, H, hd, L). */
+KVQ_API int kvq_mix_v_softmax(int bits, const float *scores, const float *parts, int n_parts,
+                      float inv_sqrt_hd, const uint16_t *sink_scores, uint16_t *sink_probs,
+                      int n_sink, float *probs, const int32_t *mat, float *mul,
+                      const float *lut_rows, int H, int hd, int64_t L, int64_t max_len,
+                      const float *outliers, const int32_t *outlier_idx, int n_out,
+                      int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- prefill attention (the MFMA path of BASELINE config 4) ----------------------- */
 
 /* Causal self-attention of the S prompt tokens of one sequence, all heads, flash-style on the gfx950 matrix cores

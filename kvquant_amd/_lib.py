@@ -49,6 +49,8 @@ SIGNATURES = {
     "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                           _sz, _f, _vp, _i, _vp]),
     "kvq_softmax_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp]),
+    "kvq_mix_v_softmax": (_i, [_i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp, _vp, _i,
+                               _i, _vp, _sz, _vp]),
     "kvq_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "kvq_append_k_sparse_orig": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "kvq_append_v_sparse_orig": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),

@@ -506,10 +506,15 @@ class QuantV(nn.Module):
         self.vlen += S
 
 
+FUSE_SOFTMAX_INTO_MIX_V = False
+
+
 def decode_kv(kc, vc, q, k, v, sink_scores=None):
     """One decode token through a layer's compressed KV path, GPU-resident, 5 launches:
     prologue (K append | V append | K tables) -> q.K^T (+ first softmax pass) -> softmax finish -> p.V -> slab
-    reduce.
+    reduce.  (FUSE_SOFTMAX_INTO_MIX_V: the p.V kernel normalises the raw scores itself, kvq_mix_v_softmax --
+    measured SLOWER at 128K, 93 vs 88 us for the pair of launches, because every probability is then evaluated
+    twice: by the workgroup that streams its head's rows and by the one that owns its token's outliers.)
     q: [H, hd] RoPE'd query, k, v: [C] pre-RoPE key / value, all fp16 or all fp32 (no conversion
     launches).  sink_scores: optional f16 [H, n_sink] already scaled scores of the fp16 sink tokens.
     Returns (out f32 [1, H, hd], sink_probs f16 [H, n_sink] or None).  Sparse (include_sparse) caches only."""
@@ -531,10 +536,16 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     L = kc.klen - kc.first_few_fp16
     H = kc.num_heads
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
+    out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
+    if FUSE_SOFTMAX_INTO_MIX_V:
+        sink_probs = ops.score_k_mix_v(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
+                                       kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), vc.vcache, out,
+                                       vc.mix_table(), vc.outliers, vc.outlier_indices, sink_scores, kc.outliers_t,
+                                       kc.outlier_indices_t)
+        return out, sink_probs
     probs, sink_probs = ops.score_k_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
                                             kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), sink_scores,
                                             kc.outliers_t, kc.outlier_indices_t)
-    out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
               accumulate=False)
     return out, sink_probs

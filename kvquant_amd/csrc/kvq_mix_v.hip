@@ -36,6 +36,8 @@
 #include "kvq_host.h"
 #include "kvq_mix_v_rows.h"
 
+#include <hip/hip_fp16.h>
+
 #include <cstdlib>
 #ifndef KVQ_V_WGS
 #define KVQ_V_WGS 512
@@ -104,6 +106,9 @@ struct VCfg {
   static constexpr int SP_B = SP_P_B + 32768;
   static constexpr int SMEM_0 = (STAGES_B > RED_B ? STAGES_B : RED_B);
   static constexpr int SMEM_B = KVQ_V_NOSP ? SMEM_0 : (SMEM_0 > SP_B ? SMEM_0 : SP_B);
+  static constexpr int MZ_HEADS = 128;                 // fused softmax: (max, normaliser) of every head, behind everything else
+  static constexpr int MZ_B = MZ_HEADS * 8;
+  static_assert(P_B / 4 == NT, "the fused softmax converts one score per lane per chunk");
   static_assert(QR % SLOTS == 0, "slots must split the chunk's quads");
 };
 
@@ -124,16 +129,11 @@ struct MixArgs {
   int n_units;
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out)
-  // FUSED softmax (decode, q_len = 1): `p` is unused; the kernel reads the RAW scores and the per-(head, tile)
-  // (max, sum) partials of the score kernel, merges them, and converts scores to probabilities on the way
-  // (exactly the arithmetic of kvq_softmax_finish: half(expf(half(half(s) * inv) - M) / Z))
+  // FUSED softmax (decode, q_len = 1): `p` is unused; the kernel reads the RAW scores and converts them to
+  // probabilities on the way (exactly the arithmetic of kvq_softmax_finish: half(expf(half(half(s) * inv) - M) / Z))
   const float *scores;     // [H][L]
-  const float *parts;      // [H][n_parts][2]
-  int n_parts;
+  const float *mz;         // [H][2]: (max, normaliser) of every row, merged from the partials by softmax_merge_kernel
   float inv;
-  const __half *sink;      // [H][n_sink] fp16 scaled sink scores or null
-  __half *sink_probs;      // [H][n_sink]
-  int n_sink;
 #if KVQ_TRACE
   unsigned long long *trace;   // development: [block][wave][chunk][8]
 #endif
@@ -266,7 +266,7 @@ __device__ __forceinline__ DmaFast make_dma_fast(const MixArgs &a, const DmaLane
 
 template <int BITS, int PART>
 __device__ __forceinline__ void issue_fast(const MixArgs &a, const DmaFast &f, uint32_t lds0, int stage, int pstage,
-                                           const float *psrc, int64_t c0, int row_base, int h0, int b) {
+                                           const float *psrc, int64_t c0, int64_t pc0, int row_base, int h0, int b) {
   using Cfg = VCfg<BITS>;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NW = Cfg::NT / 64;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void issue_fast(const MixArgs &a, const DmaFast &f, u
   for (int k = 0; k < K_P; k++) {
     const int j = wave + k * NW;
     if (j < N_P)
-      dma4(psrc + ((int64_t)b * a.H + h0 + k * NW * (64 / Cfg::CT)) * a.L + c0, f.p, lds0 + Cfg::p_off(pstage) + j * 256);
+      dma4(psrc + ((int64_t)b * a.H + h0 + k * NW * (64 / Cfg::CT)) * a.L + pc0, f.p, lds0 + Cfg::p_off(pstage) + j * 256);
   }
 }
 
@@ -351,11 +351,31 @@ __device__ __forceinline__ unsigned vcode(const uint32_t (&w)[WORDS]) {
   else return (w[0] >> (2 * I)) & 0x3u;
 }
 
-template <int BITS>
+// 2^(d log2 e): the weights that merge the (max, sum) partials of a softmax row (as kvq_softmax.hip does)
+__device__ __forceinline__ float mz_w(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
+// raw score -> fp16-rounded probability (modeling_llama.py:873-874, 1972-1976): half(exp(half(half(raw) * inv) - M) / Z).
+// kvq_softmax_finish evaluates that with expf and a true division, ~45 VALU operations per element; every element
+// is converted twice here (dense loop and sparse phase), which at that price is 10 us of the kernel at 128K.  This form
+// costs 14: 2^(d log2 e) on the hardware exponential with the product d*log2(e) carried to ~2^-48 (hi + lo) and a
+// first-order correction, times the reciprocal of the normaliser.  <= 2 ulp from the exact fp32 quotient BEFORE the
+// fp16 rounding, i.e. about one probability in 2000 lands on the neighbouring fp16 value.
+__device__ __forceinline__ float prob_of(float raw, float inv, float M, float rZ) {
+  const float d = scaled(raw, inv) - M;                    // <= 0
+  const float t = d * 1.44269502f;
+  const float e = fmaf(d, 1.44269502f, -t) + d * 1.92596299e-8f;
+  const float r = __builtin_amdgcn_exp2f(t);               // (results below 2^-126 flush to 0: far below fp16's 6e-8)
+  return __half2float(__float2half_rn(fmaf(r, e * 0.693147182f, r) * rZ));
+}
+
+// FUSED: the second softmax pass (kvq_softmax_finish) happens inside this kernel -- the workgroups merge the
+// (max, sum) partials of the score kernel themselves and convert raw scores to probabilities in LDS, one chunk
+// ahead of the look-up loop; the [H][L] probabilities never exist in memory (saves a launch, 13 us and 2 x 4 bytes
+// per token and head of traffic at 128K).
+template <int BITS, bool FUSED>
 __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   using Cfg = VCfg<BITS>;
   constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B + KVQ_PAD_LDS];  // static: LDS offsets fold into ds immediates
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B + (FUSED ? Cfg::MZ_B : 0) + KVQ_PAD_LDS];  // static: LDS offsets fold into ds immediates
   unsigned char *stage0 = smem;
 
   const int tid = threadIdx.x;
@@ -380,7 +400,36 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 
   const uint32_t lds0 = lds_addr(smem);
   const DmaLane dl = make_dma_lane<BITS>();
-  issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b);
+  issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
+  const float2 *mz = reinterpret_cast<const float2 *>(smem + Cfg::SMEM_B);   // FUSED: (max, normaliser) per head
+  float myM = 0.f, myZ = 1.f;                                                  // ... of the head this lane converts for
+  if constexpr (FUSED) {
+    // raw scores of the first two chunks -> p buffers 0 and 1 (chunk c lives in buffer c % 3)
+    issue_p<BITS>(a.scores, a, dl, lds0 + Cfg::p_off(0), t0, h0, b);
+    if (n_chunks > 1) issue_p<BITS>(a.scores, a, dl, lds0 + Cfg::p_off(1), t0 + CT, h0, b);
+    // (max, normaliser) of every head -> LDS (the sparse phase needs all of them), this lane's head -> registers
+    float2 *mzw = reinterpret_cast<float2 *>(smem + Cfg::SMEM_B);
+    for (int h = tid; h < a.H; h += Cfg::NT) {
+      const float2 t = reinterpret_cast<const float2 *>(a.mz)[h];
+      mzw[h] = make_float2(t.x, 1.0f / t.y);     // (max, 1 / normaliser)
+    }
+    {
+      const int hr = tid / CT;                       // the element of a p buffer this lane converts: [hr][tid % CT]
+      const int hc = h0 + hr < a.H ? h0 + hr : a.H - 1;
+      const float2 t = reinterpret_cast<const float2 *>(a.mz)[hc];
+      myM = t.x;
+      myZ = 1.0f / t.y;
+    }
+    dma_wait_all();
+    __syncthreads();          // mz visible, the scores of chunk 0 (and 1) landed
+  }
+  // FUSED: raw score -> probability in place, one element per lane; tokens at or past the end of the range get 0
+  auto convert_p = [&](int pbuf, int64_t c0) {
+    float *pp = reinterpret_cast<float *>(smem + Cfg::p_off(pbuf)) + tid;
+    const float x = *pp;
+    *pp = (c0 + (tid % CT) < t1) ? prob_of(x, a.inv, myM, myZ) : 0.f;
+  };
+  if constexpr (FUSED) convert_p(0, t0);   // (visible after the first chunk's barrier)
   const DmaFast df = make_dma_fast<BITS>(a, dl);
   // chunks whose DMA needs no clamps (see issue_fast): all that start at or before `fast_end`
   int64_t fast_end = (a.max_len < a.L ? a.max_len : a.L) - CT;
@@ -424,7 +473,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     const unsigned nent = (unsigned)ns * (unsigned)a.n_out;  // < 2^31
     const float *ov = a.outliers + s0 * a.n_out;
     const int32_t *oi = a.idx + s0 * a.n_out;
-    const float *p0 = a.p + s0;
+    const float *p0 = (FUSED ? a.scores : a.p) + s0;   // FUSED: raw scores, converted on the way
     float *sslab = a.sparse_partial + (int64_t)blockIdx.x * C;
     const bool staged = ns <= 320 && (int64_t)(ns | 1) * a.H * 4 <= Cfg::SP_P_B;
     constexpr int RB = KVQ_V_RB;    // entries per lane per round, all loads of a round in flight together (24: a 272-token share at n_out = 42 in one round)
@@ -466,7 +515,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #pragma unroll
           for (int m = 0; m < 5; m++) {
             const int h = hb + wv + 8 * k, tl = ln + 64 * m;
-            if (h < a.H && tl < ns) pl[h * nsp + tl] = v[k][m];
+            if (h < a.H && tl < ns) pl[h * nsp + tl] = (FUSED && !(KVQ_V_DBG & 128)) ? prob_of(v[k][m], a.inv, mz[h].x, mz[h].y) : v[k][m];
           }
       }
     }
@@ -490,7 +539,8 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
           const unsigned tl = __umulhi(ec, a.n_out_magic);
           unsigned h = (unsigned)row[j] >> 7;
           h = h < (unsigned)a.H ? h : (unsigned)a.H - 1u;
-          pt[j] = staged ? pl[h * nsp + tl] : p0[(int64_t)h * a.L + tl];
+          pt[j] = staged ? pl[h * nsp + tl]
+                         : (FUSED ? prob_of(p0[(int64_t)h * a.L + tl], a.inv, mz[h].x, mz[h].y) : p0[(int64_t)h * a.L + tl]);
         }
 #pragma unroll
         for (int j = 0; j < RB; j++) {
@@ -568,16 +618,33 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #endif
     const int64_t cn0 = (KVQ_V_DBG & 4) ? t0 : c0 + CT;                   // start of the next chunk
     const bool more = ci + 1 < n_chunks && (!(KVQ_V_DBG & 2) || a.q_len > 1000);
-    const bool spread = BITS == 4 && KVQ_V_ASM && KVQ_V_SPREAD && cn0 <= fast_end;   // (wave-uniform)
-    if (more && !spread) issue_chunk<BITS>(a, dl, lds0, 1 - stage, cn0, row_base, n_rows_valid, h0, b);
+    // FUSED: the scores travel one chunk further ahead than the rows (chunk ci+2 -> p buffer (ci+2) % 3)
+    const int pcur = FUSED ? ci % 3 : stage;
+    const int pnext = FUSED ? (ci + 2) % 3 : 1 - stage;
+    const int64_t pc0 = FUSED ? cn0 + CT : cn0;
+    const bool spread = BITS == 4 && KVQ_V_ASM && KVQ_V_SPREAD && pc0 <= fast_end;   // (wave-uniform)
+    if (more && !spread) {
+      issue_chunk<BITS>(a, dl, lds0, 1 - stage, cn0, row_base, n_rows_valid, h0, b, !FUSED);
+      if (FUSED && ci + 2 < n_chunks) issue_p<BITS>(a.scores, a, dl, lds0 + Cfg::p_off(pnext), pc0, h0, b);
+    }
+    // the next chunk's scores landed with this chunk's rows (issued one chunk earlier): convert them now -- in the
+    // hand-scheduled loop the LDS read is issued here and the value is used two quads later, behind the look-ups
+    constexpr bool CONV_IN_LOOP = FUSED && BITS == 4 && KVQ_V_ASM && Cfg::QPL >= 3;
+    float raw_next = 0.f;
+    const uint32_t conv_addr = (uint32_t)(tid * 4 + ((ci + 1) % 3) * Cfg::P_B);
+    if constexpr (CONV_IN_LOOP) {
+      if (more) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(raw_next) : "v"(conv_addr), "n"(Cfg::p_off(0)) : "memory");
+    } else if (FUSED && more) {
+      convert_p((ci + 1) % 3, cn0);
+    }
 #if KVQ_TRACE
     stamp(3);
 #endif
     const unsigned char *tile = smem + Cfg::tile_off(stage);
     const unsigned char *lutb = smem + Cfg::lut_off(stage);
-    float *pb = reinterpret_cast<float *>(smem + Cfg::p_off(stage));
+    float *pb = reinterpret_cast<float *>(smem + Cfg::p_off(pcur));
     const int rem = (int)(t1 - c0);       // tokens of this range left in the chunk
-    if (rem < CT) {                       // ragged last chunk: zero the probabilities past the end once
+    if (!FUSED && rem < CT) {             // ragged last chunk: zero the probabilities past the end once
       for (int i = tid; i < Cfg::HW * CT; i += Cfg::NT)
         if (i % CT >= rem) pb[i] = 0.f;
       __syncthreads();
@@ -586,29 +653,37 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     if constexpr (BITS == 4 && KVQ_V_ASM) {
       constexpr int S0 = Cfg::tile_off(stage);                  // tile
       constexpr int L0 = Cfg::lut_off(stage);                   // codebook rows (row (qq*4+e)*SLOTS + slot)
-      constexpr int P0 = Cfg::p_off(stage);                     // probabilities
+      constexpr int P0 = Cfg::p_off(0);                         // probabilities (buffer offset in the address register)
+      const uint32_t paddr_c = paddr + (uint32_t)(pcur * Cfg::P_B);
       constexpr int TS = Cfg::SLOTS * N * 4;                    // bytes between the rows of consecutive tokens of a slot
       uint4 wq[2];
       float4 pq[2];
       lds_read16<S0>(wq[0], taddr[0]);
-      lds_read16<P0>(pq[0], paddr);
+      lds_read16<P0>(pq[0], paddr_c);
       static_for<0, Cfg::QPL>([&](auto QQ) {
         constexpr int qq = decltype(QQ)::value;
         constexpr int cur = qq & 1;
         uint32_t we, wo, ua[8], ub[8];
         float va[8], vb[8];
         lds_wait<0>();                                          // this quad's words and probabilities
+        if constexpr (CONV_IN_LOOP && qq == 1) asm volatile("" : "+v"(raw_next));   // (landed: everything older than this wait has)
+        if constexpr (CONV_IN_LOOP && qq == 2) {
+          if (more) {
+            float pr = (KVQ_V_DBG & 64) ? raw_next : ((cn0 + (tid % CT) < t1) ? prob_of(raw_next, a.inv, myM, myZ) : 0.f);
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(conv_addr), "v"(pr), "n"(Cfg::p_off(0)) : "memory");
+          }
+        }
         nib_prep(we, wo, wq[cur].x, slotpat); nib_extract(ua, we, wo); lut_read8<L0 + (qq * 4 + 0) * TS>(va, ua);
         nib_prep(we, wo, wq[cur].y, slotpat); nib_extract(ub, we, wo); lut_read8<L0 + (qq * 4 + 1) * TS>(vb, ub);
         // a quad's share of the next chunk's DMA, behind 16 look-ups in flight (the other stage is free since the barrier)
-        if (more && spread) issue_fast<BITS, qq>(a, df, lds0, 1 - stage, 1 - stage, a.p, cn0, row_base, h0, b);
+        if (more && spread) issue_fast<BITS, qq>(a, df, lds0, 1 - stage, pnext, FUSED ? a.scores : a.p, cn0, pc0, row_base, h0, b);
         lds_wait<8>(); fmac8(acc, va, pq[cur].x);
         nib_prep(we, wo, wq[cur].z, slotpat); nib_extract(ua, we, wo); lut_read8<L0 + (qq * 4 + 2) * TS>(va, ua);
         lds_wait<8>(); fmac8(acc, vb, pq[cur].y);
         nib_prep(we, wo, wq[cur].w, slotpat); nib_extract(ub, we, wo); lut_read8<L0 + (qq * 4 + 3) * TS>(vb, ub);
         if constexpr (qq + 1 < Cfg::QPL) {                      // the next quad, behind the look-ups in flight
           lds_read16<S0>(wq[1 - cur], taddr[qq + 1]);
-          lds_read16<P0 + (qq + 1) * 16>(pq[1 - cur], paddr);
+          lds_read16<P0 + (qq + 1) * 16>(pq[1 - cur], paddr_c);
           lds_wait<10>(); fmac8(acc, va, pq[cur].z);
           lds_wait<2>(); fmac8(acc, vb, pq[cur].w);
         } else {
@@ -792,6 +867,54 @@ __global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restr
   }
 }
 
+// (max, normaliser) of every softmax row from the score kernel's per-(head, tile) partials and the fp16 sink scores,
+// and the sink probabilities: the part of kvq_softmax_finish that is not per token.  One workgroup per head.
+__global__ __launch_bounds__(256) void softmax_merge_kernel(const float *__restrict__ parts, int n_parts,
+                                                            const __half *__restrict__ sink, __half *__restrict__ sink_probs,
+                                                            int n_sink, float *__restrict__ mz) {
+  __shared__ float red[8];
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const float2 *pr = reinterpret_cast<const float2 *>(parts) + (int64_t)h * n_parts;
+  float M = -INFINITY, Z = 0.f;
+  for (int i0 = 0; i0 < n_parts; i0 += 4 * 256) {
+    float2 ms[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + tid + 256 * k;
+      ms[k] = i < n_parts ? pr[i] : make_float2(-INFINITY, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (ms[k].x > -INFINITY) {
+        const float mn = fmaxf(M, ms[k].x);
+        Z = Z * mz_w(M - mn) + ms[k].y * mz_w(ms[k].x - mn);
+        M = mn;
+      }
+  }
+  for (int i = tid; i < n_sink; i += 256) {
+    const float x = __half2float(sink[h * n_sink + i]);
+    const float mn = fmaxf(M, x);
+    Z = Z * expf(M - mn) + expf(x - mn);
+    M = mn;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float mo = __shfl_xor(M, d), zo = __shfl_xor(Z, d);
+    const float mn = fmaxf(M, mo);
+    Z = (mn == -INFINITY) ? 0.f : Z * mz_w(M - mn) + zo * mz_w(mo - mn);
+    M = mn;
+  }
+  if ((tid & 63) == 0) { red[tid >> 6] = M; red[4 + (tid >> 6)] = Z; }
+  __syncthreads();
+  float Mb = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float Zb = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (red[i] > -INFINITY) Zb += red[4 + i] * mz_w(red[i] - Mb);
+  if (tid == 0) { mz[2 * h] = Mb; mz[2 * h + 1] = Zb; }
+  for (int i = tid; i < n_sink; i += 256)
+    sink_probs[h * n_sink + i] = __float2half_rn(expf(__half2float(sink[h * n_sink + i]) - Mb) / Zb);
+}
+
 struct Plan {
   int64_t tr;
   int n_ranges, groups, n_units;
@@ -812,12 +935,22 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   pl.tr = tr;
   pl.n_ranges = (int)((L + tr - 1) / tr);
   if (pl.n_ranges < 1) pl.n_ranges = 1;
-  pl.bytes = ((size_t)pl.n_ranges * q_len + (size_t)pl.n_ranges * pl.groups) * H * kHeadDim * sizeof(float);
+  pl.bytes = ((size_t)pl.n_ranges * q_len + (size_t)pl.n_ranges * pl.groups) * H * kHeadDim * sizeof(float) +
+             (size_t)H * 2 * sizeof(float);   // + the (max, normaliser) pairs of the fused softmax
   return pl;
 }
 
+struct FusedSoftmax {
+  const float *scores, *parts;
+  int n_parts;
+  float inv;
+  const __half *sink;
+  __half *sink_probs;
+  int n_sink;
+};
+
 template <int BITS>
-static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st) {
+static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, const FusedSoftmax *fs = nullptr) {
   using Cfg = VCfg<BITS>;
   Plan pl = plan_mix<BITS>(a.q_len, a.H, a.L);
   a.tr = pl.tr;
@@ -825,7 +958,18 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st) {
   a.n_units = pl.n_units;
   a.sparse_partial = a.partial + (size_t)pl.n_ranges * a.q_len * a.H * kHeadDim;
   dim3 grid(pl.n_ranges * pl.groups, 1, a.q_len), block(Cfg::NT);
-  mix_v_kernel<BITS><<<grid, block, 0, st>>>(a);
+  if (fs) {
+    float *mz = a.sparse_partial + (size_t)pl.n_ranges * pl.groups * a.H * kHeadDim;   // (tail of the workspace)
+    softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz);
+    int rc0 = check_launch();
+    if (rc0) return rc0;
+    a.scores = fs->scores;
+    a.mz = mz;
+    a.inv = fs->inv;
+    mix_v_kernel<BITS, true><<<grid, block, 0, st>>>(a);
+  } else {
+    mix_v_kernel<BITS, false><<<grid, block, 0, st>>>(a);
+  }
   int rc = check_launch();
   if (rc) return rc;
   const int C = a.H * kHeadDim;
@@ -852,9 +996,16 @@ size_t kvq_mix_v_workspace_bytes(int bits, int q_len, int H, int hd, int64_t L) 
   return ws_bytes(bits, q_len, H, L > 0 ? L : 1);
 }
 
-int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const float *lut_rows, int q_len,
-              int H, int hd, int64_t L, int64_t max_len, const float *outliers, const int32_t *outlier_idx,
-              int n_out, int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+static bool mix_fast_shape(const int32_t *mat, const float *lut_rows, int H, int hd, int64_t L, int64_t max_len, int bits) {
+  return (max_len % 4 == 0) && (max_len >= 4) && ((int64_t)H * (hd / 32 * bits) * max_len < (1ll << 31)) &&
+         ((reinterpret_cast<uintptr_t>(mat) | reinterpret_cast<uintptr_t>(lut_rows)) % 16 == 0);
+}
+
+// p: the probabilities, or with `fs` the raw scores (fast shapes only)
+static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int32_t *mat, float *mul, const float *lut_rows,
+                     int q_len, int H, int hd, int64_t L, int64_t max_len, const float *outliers,
+                     const int32_t *outlier_idx, int n_out, int accumulate, void *workspace, size_t workspace_bytes,
+                     void *stream) {
   if (!p || !mat || !mul || !lut_rows || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 || L > max_len ||
       bits < 2 || bits > 4)
     return KVQ_EINVAL;
@@ -868,9 +1019,9 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
     return KVQ_OK;
   }
   if (!workspace || workspace_bytes < ws_bytes(bits, q_len, H, L)) return KVQ_EWORKSPACE;
-  const bool fast = (max_len % 4 == 0) && (max_len >= 4) && ((int64_t)H * (hd / 32 * bits) * max_len < (1ll << 31)) &&
-                    ((reinterpret_cast<uintptr_t>(mat) | reinterpret_cast<uintptr_t>(lut_rows)) % 16 == 0);
+  const bool fast = mix_fast_shape(mat, lut_rows, H, hd, L, max_len, bits);
   if (!fast) {
+    if (fs) return KVQ_EINVAL;
     MixPlan pl = plan_mix_rows(bits, q_len, H, L, sparse);
     MixVArgs a;
     a.p = p;
@@ -911,15 +1062,53 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
   a.n_units = 0;
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
+  a.scores = nullptr;
+  a.mz = nullptr;
+  a.inv = 0.f;
 #if KVQ_TRACE
   a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
   if (!a.trace) return KVQ_EINVAL;
 #endif
   switch (bits) {
-    case 4: return launch_mix<4>(a, mul, accumulate, st);
-    case 3: return launch_mix<3>(a, mul, accumulate, st);
-    default: return launch_mix<2>(a, mul, accumulate, st);
+    case 4: return launch_mix<4>(a, mul, accumulate, st, fs);
+    case 3: return launch_mix<3>(a, mul, accumulate, st, fs);
+    default: return launch_mix<2>(a, mul, accumulate, st, fs);
   }
+}
+
+int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const float *lut_rows, int q_len,
+              int H, int hd, int64_t L, int64_t max_len, const float *outliers, const int32_t *outlier_idx,
+              int n_out, int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+  return mix_v_any(bits, p, nullptr, mat, mul, lut_rows, q_len, H, hd, L, max_len, outliers, outlier_idx, n_out, accumulate,
+                   workspace, workspace_bytes, stream);
+}
+
+int kvq_mix_v_softmax(int bits, const float *scores, const float *parts, int n_parts, float inv_sqrt_hd,
+                      const uint16_t *sink_scores, uint16_t *sink_probs, int n_sink, float *probs,
+                      const int32_t *mat, float *mul, const float *lut_rows, int H, int hd, int64_t L,
+                      int64_t max_len, const float *outliers, const int32_t *outlier_idx, int n_out,
+                      int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!scores || !parts || n_parts <= 0 || n_sink < 0 || H <= 0 || L <= 0) return KVQ_EINVAL;
+  if (n_sink > 0 && (!sink_scores || !sink_probs)) return KVQ_EINVAL;
+  const bool fast = mix_fast_shape(mat, lut_rows, H, hd, L, max_len, bits) && H <= VCfg<4>::MZ_HEADS;
+  if (!fast) {
+    // shapes the streaming kernel does not take: the two passes separately
+    if (!probs) return KVQ_EINVAL;
+    int rc = kvq_softmax_finish(scores, sink_scores, parts, n_parts, probs, sink_probs, H, L, n_sink, inv_sqrt_hd, stream);
+    if (rc) return rc;
+    return mix_v_any(bits, probs, nullptr, mat, mul, lut_rows, 1, H, hd, L, max_len, outliers, outlier_idx, n_out, accumulate,
+                     workspace, workspace_bytes, stream);
+  }
+  FusedSoftmax f;
+  f.scores = scores;
+  f.parts = parts;
+  f.n_parts = n_parts;
+  f.inv = inv_sqrt_hd;
+  f.sink = reinterpret_cast<const __half *>(sink_scores);
+  f.sink_probs = reinterpret_cast<__half *>(sink_probs);
+  f.n_sink = n_sink;
+  return mix_v_any(bits, scores, &f, mat, mul, lut_rows, 1, H, hd, L, max_len, outliers, outlier_idx, n_out, accumulate,
+                   workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

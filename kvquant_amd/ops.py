@@ -440,6 +440,48 @@ def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, out
     return softmax_finish(mul[0], parts, n_parts, inv_sqrt_hd, sink_scores)
 
 
+def score_k_mix_v(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices, inv_sqrt_hd,
+                  vmat, out, vlut_rows, voutliers, voutlier_indices, sink_scores=None, koutliers_t=None,
+                  koutlier_indices_t=None):
+    """q.K^T (tables already in `ws`) -> softmax -> p.V of one decode token in two streaming launches + the slab
+    reduce: the score kernel writes raw scores and per-tile softmax partials, the p.V kernel normalises on the way
+    (kvq_mix_v_softmax).  scores [1, H, L] scratch, out f32 [1, H, hd].  Returns sink_probs (f16 [H, n_sink]) or None."""
+    n_parts = _L().kvq_score_k_softmax_parts(bits, int(L), 1 if koutliers is not None else 0)
+    if n_parts == 0 or voutliers is None:
+        probs, sink_probs = score_k_softmax(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers,
+                                            koutlier_indices, inv_sqrt_hd, sink_scores, koutliers_t,
+                                            koutlier_indices_t)
+        mix_v(bits, probs.unsqueeze(0), vmat, out, vlut_rows, L, voutliers, voutlier_indices, accumulate=False)
+        return sink_probs
+    parts = score_k_prepared_softmax(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices,
+                                     inv_sqrt_hd, n_parts, koutliers_t, koutlier_indices_t)
+    return mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, vmat, out, vlut_rows, L, voutliers,
+                         voutlier_indices, sink_scores)
+
+
+def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows, L, outliers, outlier_indices,
+                  sink_scores=None):
+    """kvq_mix_v_softmax: raw scores [1, H, L] + the score kernel's softmax partials -> mul f32 [1, H, hd]
+    (overwritten); returns sink_probs (f16 [H, n_sink]) or None."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    n_sink = 0 if sink_scores is None else sink_scores.shape[1]
+    sink_probs = None if n_sink == 0 else torch.empty_like(sink_scores)
+    with _Dev(mat):
+        nbytes = _L().kvq_mix_v_workspace_bytes(bits, 1, H, hd, int(L))
+        wsv = _workspace(mat.device, nbytes)
+        probs = None
+        if max_len % 4 != 0 or H > 128:      # the two-pass route inside the library needs room for the probabilities
+            probs = _workspace(mat.device, H * int(L) * 4, slot="probs")
+        _lib.check(_L().kvq_mix_v_softmax(
+            bits, _f(scores, "scores"), parts.data_ptr(), n_parts, float(inv_sqrt_hd),
+            None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"),
+            None if n_sink == 0 else sink_probs.data_ptr(), n_sink, None if probs is None else probs.data_ptr(),
+            _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), H, hd, int(L), max_len,
+            _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outliers.shape[1], 0, wsv.data_ptr(),
+            wsv.numel(), _stream()), "kvq_mix_v_softmax")
+    return sink_probs
+
+
 # ---- prefill attention on the matrix cores ----------------------------------------------------------------------
 def prefill_attention(q, k, v, softmax_scale=None):
     """causal attention of a prompt: q, k, v fp16 [H, S, 128] views (any strides with a contiguous last dimension,

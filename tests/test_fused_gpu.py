@@ -167,3 +167,48 @@ def test_score_softmax_fused_matches_two_pass(gpu, bits, L, n_sink):
     assert bool((d <= p4.abs() * 2e-3 + 1e-7).all()), float(d.max())
     if n_sink:
         assert bool(((sp3.float() - sp4.float()).abs() <= sp4.float().abs() * 2e-3 + 1e-7).all())
+
+
+@pytest.mark.parametrize("bits,L,max_len,n_sink", [(4, 5000, 5056, 0), (4, 777, 1024, 5), (4, 31, 64, 0), (4, 1, 64, 3),
+                                                    (3, 3000, 3072, 0), (3, 100, 128, 5), (2, 2100, 2112, 0),
+                                                    (4, 3000, 3003, 0), (4, 40000, 40064, 0)])
+def test_mix_v_softmax_matches_two_passes(bits, L, max_len, n_sink):
+    """kvq_mix_v_softmax (the second softmax pass inside the p.V kernel) against kvq_softmax_finish + kvq_mix_v on the
+    same raw scores and partials: same arithmetic per element, the normaliser merged in another order -- differences
+    are last-bit effects on fp16-rounded probabilities.  Covers sinks, ragged ranges, L smaller than a chunk, the
+    shape that takes the two-pass route inside the library (max_len % 4 != 0) and every bit width."""
+    import math
+    from kvquant_amd import ops
+    dev = torch.device("cuda:0")
+    H, HD, C = 32, 128, 4096
+    n = 2 ** bits
+    W = HD // 32 * bits
+    g = torch.Generator(device="cuda").manual_seed(L + bits)
+    kmat = torch.randint(-2 ** 31, 2 ** 31 - 1, (H, W, max_len), device=dev, dtype=torch.int64, generator=g).to(torch.int32)
+    vmat = torch.randint(-2 ** 31, 2 ** 31 - 1, (H, W, max_len), device=dev, dtype=torch.int64, generator=g).to(torch.int32)
+    rows = (torch.randn(max_len, n, device=dev, generator=g) * 0.5).sort(dim=-1).values.contiguous()
+    lut = torch.randn(H, HD, n, device=dev, generator=g).sort(dim=-1).values.contiguous()
+    vals = {}
+    for nm in ("k", "v"):
+        vals[nm] = torch.randn(max_len, 42, device=dev, generator=g) * 0.3
+        vals[nm + "i"] = torch.sort(torch.randint(0, C, (max_len, 42), device=dev, generator=g), dim=-1).values.to(torch.int32)
+    q = torch.randn(1, H, HD, device=dev, generator=g) * 3
+    inv = 1.0 / math.sqrt(HD)
+    sink = (torch.randn(H, n_sink, device=dev, generator=g) * 2).half() if n_sink else None
+    s = torch.zeros(1, H, L, device=dev)
+    ops.score_k(bits, q, kmat, torch.zeros(1, H, 1, device=dev), lut, 1, 10000.0, 0, accumulate=False)   # tables -> workspace
+    ws = ops._workspace(dev, ops._L().kvq_score_k_workspace_bytes(bits, 1, H), slot="score")
+    n_parts = ops._L().kvq_score_k_softmax_parts(bits, L, 1)
+    assert n_parts > 0
+    parts = ops.score_k_prepared_softmax(bits, kmat, s, lut, L, 10000.0, 0, ws, vals["k"], vals["ki"], inv, n_parts)
+    probs, sp_ref = ops.softmax_finish(s[0], parts, n_parts, inv, sink)
+    ref = torch.zeros(1, H, HD, device=dev)
+    ops.mix_v(bits, probs.unsqueeze(0), vmat, ref, rows, L, vals["v"], vals["vi"], accumulate=False)
+    out = torch.full((1, H, HD), 7.0, device=dev)
+    sp = ops.score_k_mix_v(bits, kmat, s, lut, L, 10000.0, 0, ws, vals["k"], vals["ki"], inv, vmat, out, rows,
+                           vals["v"], vals["vi"], sink)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item() + 1e-6
+    assert (out - ref).abs().max().item() <= 2e-3 * scale
+    if n_sink:
+        assert (sp.float() - sp_ref.float()).abs().max().item() <= 2e-3 * (sp_ref.float().abs().max().item() + 1e-6)

@@ -19,9 +19,20 @@ p = torch.softmax(torch.randn(1, H, L, device=dev, generator=g), dim=-1).contigu
 trace = torch.zeros(512 * 8 * 16, dtype=torch.int64, device=dev)
 os.environ["KVQ_TRACE_PTR"] = str(trace.data_ptr())
 out = torch.zeros(1, H, HD, device=dev)
+fused = os.environ.get("FUSED") == "1"
+if fused:
+    raw = torch.randn(1, H, L, device=dev, generator=g) * 30
+    inv = 1.0 / math.sqrt(HD)
+    sc = (raw[0].half() * torch.tensor(inv, device=dev).half()).float()
+    M = sc.max(dim=-1).values
+    Z = torch.exp(sc - M[:, None]).sum(dim=-1)
+    parts = torch.stack((M, Z), dim=-1).reshape(H, 1, 2).contiguous()
 for it in range(3):
     trace.zero_()
-    ops.mix_v(bits, p, v, out, rows, L, vv, vi, accumulate=False)
+    if fused:
+        ops.mix_v_softmax(bits, raw, parts, 1, inv, v, out, rows, L, vv, vi)
+    else:
+        ops.mix_v(bits, p, v, out, rows, L, vv, vi, accumulate=False)
 torch.cuda.synchronize()
 t = trace.view(512, 8, 16).cpu().double()
 nc = t[:, 0, 11].max()

@@ -59,9 +59,14 @@ def run(bits, L, iters=30, nrot=2):
         d = caches[i % nrot]
         ops.mix_v(bits, state["p"].unsqueeze(0), d["v"], out, d["rows"], L, d["vvals"], d["vidx"], accumulate=False)
 
+    def vfcall(i):
+        d = caches[i % nrot]
+        ops.mix_v_softmax(bits, s, state["parts"], n_parts, inv, d["v"], out, d["rows"], L, d["vvals"], d["vidx"])
+
     res = {}
     for nm, fn, bpt in (("score_k", kcall, C * bits // 8 + 336 + 128), ("softmax_finish", fcall, 256),
-                        ("mix_v", vcall, C * bits // 8 + 336 + 4 * n + 128)):
+                        ("mix_v", vcall, C * bits // 8 + 336 + 4 * n + 128),
+                        ("mix_v_softmax", vfcall, C * bits // 8 + 336 + 4 * n + 128)):
         for i in range(3):
             fn(i)
         torch.cuda.synchronize()
