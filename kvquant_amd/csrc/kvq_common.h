@@ -19,6 +19,23 @@ __device__ __forceinline__ float scaled(float raw, float inv) {
   return __half2float(__float2half_rn(h * inv));
 }
 
+// exp(d) for d <= 0 on the hardware exponential: 2^(d log2 e) with the product carried to ~2^-48 (hi + lo) and a
+// first-order correction -- 7 VALU operations against ~25 for expf, <= 1.5 ulp (results below 2^-126 flush to 0).
+__device__ __forceinline__ float exp_neg(float d) {
+  const float t = d * 1.44269502f;
+  const float e = fmaf(d, 1.44269502f, -t) + d * 1.92596299e-8f;
+  const float r = __builtin_amdgcn_exp2f(t);
+  return fmaf(r, e * 0.693147182f, r);
+}
+// scaled score -> fp16-rounded probability, exp(x - M) / Z rounded to fp16 (modeling_llama.py:1976), with rZ = 1/Z.
+// The softmax passes evaluate 4 M of these per layer at 128K: with expf and a true division (~45 operations) the
+// normalising kernel is VALU bound (14 us); this form costs 12 and is <= 2 ulp from the exact fp32 quotient BEFORE the
+// fp16 rounding -- about one probability in 2000 lands on the neighbouring fp16 value, the scale of the difference
+// between two exact-to-an-ulp softmax implementations (torch's on the GPU and libm on the host differ the same way).
+__device__ __forceinline__ float prob_fp16(float x, float M, float rZ) {
+  return __half2float(__float2half_rn(exp_neg(x - M) * rZ));
+}
+
 constexpr int kWave = 64;
 constexpr int kHeadDim = 128;  // score / mix kernels (reference BLOCKWIDTH, KCU:43)
 

@@ -353,19 +353,8 @@ __device__ __forceinline__ unsigned vcode(const uint32_t (&w)[WORDS]) {
 
 // 2^(d log2 e): the weights that merge the (max, sum) partials of a softmax row (as kvq_softmax.hip does)
 __device__ __forceinline__ float mz_w(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
-// raw score -> fp16-rounded probability (modeling_llama.py:873-874, 1972-1976): half(exp(half(half(raw) * inv) - M) / Z).
-// kvq_softmax_finish evaluates that with expf and a true division, ~45 VALU operations per element; every element
-// is converted twice here (dense loop and sparse phase), which at that price is 10 us of the kernel at 128K.  This form
-// costs 14: 2^(d log2 e) on the hardware exponential with the product d*log2(e) carried to ~2^-48 (hi + lo) and a
-// first-order correction, times the reciprocal of the normaliser.  <= 2 ulp from the exact fp32 quotient BEFORE the
-// fp16 rounding, i.e. about one probability in 2000 lands on the neighbouring fp16 value.
-__device__ __forceinline__ float prob_of(float raw, float inv, float M, float rZ) {
-  const float d = scaled(raw, inv) - M;                    // <= 0
-  const float t = d * 1.44269502f;
-  const float e = fmaf(d, 1.44269502f, -t) + d * 1.92596299e-8f;
-  const float r = __builtin_amdgcn_exp2f(t);               // (results below 2^-126 flush to 0: far below fp16's 6e-8)
-  return __half2float(__float2half_rn(fmaf(r, e * 0.693147182f, r) * rZ));
-}
+// raw score -> fp16-rounded probability, the arithmetic of kvq_softmax_finish (modeling_llama.py:873-874, 1972-1976)
+__device__ __forceinline__ float prob_of(float raw, float inv, float M, float rZ) { return prob_fp16(scaled(raw, inv), M, rZ); }
 
 // FUSED: the second softmax pass (kvq_softmax_finish) happens inside this kernel -- the workgroups merge the
 // (max, sum) partials of the score kernel themselves and convert raw scores to probabilities in LDS, one chunk
@@ -829,29 +818,34 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #endif
 }
 
-// mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  32 channels x 32 range lanes per block (the pass is
-// bound by memory latency: ~700 slabs at 128K, so few slabs per lane and all of a lane's loads in flight).
+// mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  16 channels x 64 slab lanes per block: 256 blocks at C = 4096
+// (one per CU), 64-byte row segments, all of a lane's loads in flight (the pass is bound by memory latency:
+// ~770 slabs at 128K = 12 per lane).
 __global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restrict__ partial,
                                                             const float *__restrict__ sparse_partial,
                                                             float *__restrict__ mul, int n_ranges, int n_sparse,
                                                             int q_len, int C, int accumulate) {
-  __shared__ float red[32][33];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float red[64][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   const int b = blockIdx.y;
   float s = 0.f;
   if (c < C) {
-    // dense slabs [r][b][c] and (query row 0 only) sparse slabs [k][c], 8 loads in flight per lane
+    // dense slabs [r][b][c] and (query row 0 only) sparse slabs [k][c], 8 loads in flight per lane and array
     auto run = [&](const float *src, int64_t stride, int n) {
       int r = rg;
-      for (; r + 7 * 32 < n; r += 8 * 32) {
+      for (; r + 7 * 64 < n; r += 8 * 64) {
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(r + 32 * k) * stride];
+        for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(r + 64 * k) * stride];
 #pragma unroll
         for (int k = 0; k < 8; k++) s += v[k];
       }
-      for (; r < n; r += 32) s += src[(int64_t)r * stride];
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = (r + 64 * k < n) ? src[(int64_t)(r + 64 * k) * stride] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += v[k];
     };
     run(partial + (int64_t)b * C + c, (int64_t)q_len * C, n_ranges);
     if (b == 0 && n_sparse > 0) run(sparse_partial + c, C, n_sparse);
@@ -861,7 +855,7 @@ __global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restr
   if (rg == 0 && c < C) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 32; k++) t += red[k][cl];
+    for (int k = 0; k < 64; k++) t += red[k][cl];
     if (accumulate) t += mul[(int64_t)b * C + c];
     mul[(int64_t)b * C + c] = t;
   }
@@ -912,7 +906,7 @@ __global__ __launch_bounds__(256) void softmax_merge_kernel(const float *__restr
   for (int i = 0; i < 4; i++) if (red[i] > -INFINITY) Zb += red[4 + i] * mz_w(red[i] - Mb);
   if (tid == 0) { mz[2 * h] = Mb; mz[2 * h + 1] = Zb; }
   for (int i = tid; i < n_sink; i += 256)
-    sink_probs[h * n_sink + i] = __float2half_rn(expf(__half2float(sink[h * n_sink + i]) - Mb) / Zb);
+    sink_probs[h * n_sink + i] = __float2half_rn(prob_fp16(__half2float(sink[h * n_sink + i]), Mb, 1.0f / Zb));
 }
 
 struct Plan {
@@ -973,7 +967,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   int rc = check_launch();
   if (rc) return rc;
   const int C = a.H * kHeadDim;
-  dim3 rgrid((C + 31) / 32, a.q_len);
+  dim3 rgrid((C + 15) / 16, a.q_len);
   mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, a.sparse_partial, mul, pl.n_ranges,
                                              a.outliers ? pl.n_ranges * pl.groups : 0, a.q_len, C, accumulate);
   return check_launch();

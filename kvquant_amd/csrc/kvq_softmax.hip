@@ -136,7 +136,8 @@ __global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restri
       M = mn;
     }
   block_merge<NT / 64>(M, Z, red);
-  auto f = [&](float x) { return __half2float(__float2half_rn(expf(scaled(x, inv) - M) / Z)); };
+  const float rZ = 1.0f / Z;
+  auto f = [&](float x) { return prob_fp16(scaled(x, inv), M, rZ); };
   if (vec) {
     if ((int64_t)threadIdx.x < ta - t0) out[t0 + threadIdx.x] = f(row[t0 + threadIdx.x]);
     int64_t t = tv;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restri
   }
   if (sp == 0)
     for (int i = threadIdx.x; i < n_sink; i += NT)
-      sink_probs[h * n_sink + i] = __float2half_rn(expf(__half2float(sink[h * n_sink + i]) - M) / Z);
+      sink_probs[h * n_sink + i] = __float2half_rn(prob_fp16(__half2float(sink[h * n_sink + i]), M, rZ));
 }
 
 static int pick_split(int H, int64_t L) {
