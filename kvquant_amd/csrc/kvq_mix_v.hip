@@ -339,9 +339,48 @@ __device__ __forceinline__ void fmac8(float (&a)[8], const float (&v)[8], float 
                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
                : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(p));
 }
+template <int O, int NA>
+__device__ __forceinline__ void fmac8_at(float (&a)[NA], const float (&v)[8], float p) {
+  asm volatile("v_fmac_f32 %0, %8, %16\n\tv_fmac_f32 %1, %9, %16\n\tv_fmac_f32 %2, %10, %16\n\tv_fmac_f32 %3, %11, %16\n\t"
+               "v_fmac_f32 %4, %12, %16\n\tv_fmac_f32 %5, %13, %16\n\tv_fmac_f32 %6, %14, %16\n\tv_fmac_f32 %7, %15, %16"
+               : "+v"(a[O]), "+v"(a[O + 1]), "+v"(a[O + 2]), "+v"(a[O + 3]), "+v"(a[O + 4]), "+v"(a[O + 5]), "+v"(a[O + 6]), "+v"(a[O + 7])
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(p));
+}
 template <int N>
 __device__ __forceinline__ void lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- 3 bit: the 32 codes of a unit are one 96-bit stream over three words; a lane decodes 16 of them (its half).
+// `src` holds consecutive 3-bit codes from bit 0: the even ones masked in place and shifted left by 2, the odd ones
+// shifted right by 1 and masked, land as code*4 in bits [6j+2, 6j+5) of 6-bit fields -- bit 6j+5 takes the slot's table
+// offset (32 bytes), so ONE v_bfe_u32 per code yields the complete variable part of its look-up address.
+__device__ __forceinline__ void tri_prep(uint32_t &ev, uint32_t &od, uint32_t src, uint32_t slotpat) {
+  asm volatile("v_and_b32 %0, %3, %2\n\tv_lshrrev_b32 %1, 1, %2\n\tv_lshl_or_b32 %0, %0, 2, %5\n\tv_and_or_b32 %1, %1, %4, %5"
+               : "=&v"(ev), "=&v"(od) : "v"(src), "s"(0x071C71C7u), "s"(0x1C71C71Cu), "v"(slotpat));
+}
+// fields 0..3 of (ev, od) interleaved: codes 0..7 of the stream
+__device__ __forceinline__ void tri_extract_a(uint32_t (&u)[8], uint32_t ev, uint32_t od) {
+  asm volatile("v_and_b32 %0, 63, %8\n\tv_and_b32 %1, 63, %9\n\tv_bfe_u32 %2, %8, 6, 6\n\tv_bfe_u32 %3, %9, 6, 6\n\t"
+               "v_bfe_u32 %4, %8, 12, 6\n\tv_bfe_u32 %5, %9, 12, 6\n\tv_bfe_u32 %6, %8, 18, 6\n\tv_bfe_u32 %7, %9, 18, 6"
+               : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+               : "v"(ev), "v"(od));
+}
+// field 4 of (ev, od) (codes 8, 9) and fields 0..2 of the second pair (codes 10..15)
+__device__ __forceinline__ void tri_extract_b(uint32_t (&u)[8], uint32_t ev, uint32_t od, uint32_t ev2, uint32_t od2) {
+  asm volatile("v_bfe_u32 %0, %8, 24, 6\n\tv_bfe_u32 %1, %9, 24, 6\n\tv_and_b32 %2, 63, %10\n\tv_and_b32 %3, 63, %11\n\t"
+               "v_bfe_u32 %4, %10, 6, 6\n\tv_bfe_u32 %5, %11, 6, 6\n\tv_bfe_u32 %6, %10, 12, 6\n\tv_bfe_u32 %7, %11, 12, 6"
+               : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+               : "v"(ev), "v"(od), "v"(ev2), "v"(od2));
+}
+// the two 3-bit streams of a lane's half: codes [0, 10) and [10, 16) of the half, from the unit's three words
+//   half 0 (channels 0..15):  bits 0.. of w0, and bits 30.. of (w1:w0);   half 1 (16..31): bits 16.. of (w2:w1), bits 14.. of w2
+__device__ __forceinline__ void tri_streams(uint32_t &s1, uint32_t &s2, uint32_t w0, uint32_t w1, uint32_t w2, int hf) {
+  if (hf == 0) {   // (wave-uniform)
+    asm volatile("v_mov_b32 %0, %2\n\tv_alignbit_b32 %1, %3, %2, 30" : "=&v"(s1), "=&v"(s2) : "v"(w0), "v"(w1));
+  } else {
+    asm volatile("v_alignbit_b32 %0, %3, %2, 16\n\tv_lshrrev_b32 %1, 14, %3" : "=&v"(s1), "=&v"(s2) : "v"(w1), "v"(w2));
+  }
 }
 
 template <int BITS, int I, int WORDS>
@@ -574,14 +613,17 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   // slot pattern OR-ed into the pre-masked nibble bytes (4-bit fast path): byte = slot*64 + code*4
   const uint32_t slotpat = (uint32_t)sl * 0x40404040u;
 
-  // 4 bit, hand-scheduled loop: the lane's LDS addresses inside a stage do not change with the chunk
-  uint32_t taddr[Cfg::QPL];   // its 16-byte quads of the tile
-  uint32_t paddr = 0;         // the probabilities of its head for its slot's tokens
-  if constexpr (BITS == 4 && KVQ_V_ASM) {
+  // hand-scheduled loops (3 / 4 bit): the lane's LDS addresses inside a stage do not change with the chunk
+  constexpr bool ASM_LOOP = (BITS == 4 || BITS == 3) && KVQ_V_ASM;
+  uint32_t taddr[Cfg::QPL][WORDS];   // its 16-byte quads of the tile
+  uint32_t paddr = 0;                // the probabilities of its head for its slot's tokens
+  if constexpr (ASM_LOOP) {
     if (lds0 != 0) __builtin_trap();   // (the instruction immediates below assume the one static LDS array at 0)
 #pragma unroll
     for (int qq = 0; qq < Cfg::QPL; qq++)
-      taddr[qq] = (uint32_t)(rowoff[0] + (((sl * Cfg::QPL + qq + rot[0]) & (Cfg::QR - 1)) << 4));
+#pragma unroll
+      for (int wi = 0; wi < WORDS; wi++)
+        taddr[qq][wi] = (uint32_t)(rowoff[wi] + (((sl * Cfg::QPL + qq + rot[wi]) & (Cfg::QR - 1)) << 4));
     paddr = (uint32_t)((hl * CT + sl * Cfg::QPL * 4) * 4);
   }
 
@@ -611,7 +653,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     const int pcur = FUSED ? ci % 3 : stage;
     const int pnext = FUSED ? (ci + 2) % 3 : 1 - stage;
     const int64_t pc0 = FUSED ? cn0 + CT : cn0;
-    const bool spread = BITS == 4 && KVQ_V_ASM && KVQ_V_SPREAD && pc0 <= fast_end;   // (wave-uniform)
+    const bool spread = ASM_LOOP && KVQ_V_SPREAD && pc0 <= fast_end;   // (wave-uniform)
     if (more && !spread) {
       issue_chunk<BITS>(a, dl, lds0, 1 - stage, cn0, row_base, n_rows_valid, h0, b, !FUSED);
       if (FUSED && ci + 2 < n_chunks) issue_p<BITS>(a.scores, a, dl, lds0 + Cfg::p_off(pnext), pc0, h0, b);
@@ -647,7 +689,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       constexpr int TS = Cfg::SLOTS * N * 4;                    // bytes between the rows of consecutive tokens of a slot
       uint4 wq[2];
       float4 pq[2];
-      lds_read16<S0>(wq[0], taddr[0]);
+      lds_read16<S0>(wq[0], taddr[0][0]);
       lds_read16<P0>(pq[0], paddr_c);
       static_for<0, Cfg::QPL>([&](auto QQ) {
         constexpr int qq = decltype(QQ)::value;
@@ -671,13 +713,76 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
         lds_wait<8>(); fmac8(acc, vb, pq[cur].y);
         nib_prep(we, wo, wq[cur].w, slotpat); nib_extract(ub, we, wo); lut_read8<L0 + (qq * 4 + 3) * TS>(vb, ub);
         if constexpr (qq + 1 < Cfg::QPL) {                      // the next quad, behind the look-ups in flight
-          lds_read16<S0>(wq[1 - cur], taddr[qq + 1]);
+          lds_read16<S0>(wq[1 - cur], taddr[qq + 1][0]);
           lds_read16<P0 + (qq + 1) * 16>(pq[1 - cur], paddr_c);
           lds_wait<10>(); fmac8(acc, va, pq[cur].z);
           lds_wait<2>(); fmac8(acc, vb, pq[cur].w);
         } else {
           lds_wait<8>(); fmac8(acc, va, pq[cur].z);
           lds_wait<0>(); fmac8(acc, vb, pq[cur].w);
+        }
+      });
+#if KVQ_TRACE
+      stamp(4);
+#endif
+      return;
+    }
+    if constexpr (BITS == 3 && KVQ_V_ASM) {
+      // per token: two groups of 8 look-ups (codes 0..7 and 8..15 of the lane's half); the groups of token t+1 are in
+      // flight while token t is accumulated, as in the 4-bit loop
+      constexpr int S0 = Cfg::tile_off(stage);
+      constexpr int L0 = Cfg::lut_off(stage);
+      constexpr int P0 = Cfg::p_off(0);
+      constexpr int TS = Cfg::SLOTS * N * 4;                    // bytes between the rows of consecutive tokens of a slot
+      const uint32_t paddr_c = paddr + (uint32_t)(pcur * Cfg::P_B);
+      const uint32_t slot3 = (uint32_t)sl * 0x20820820u;        // the slot's row offset (N*4 = 32 bytes) in every 6-bit field
+      uint4 wq[2][3];
+      float4 pq[2];
+#pragma unroll
+      for (int wi = 0; wi < 3; wi++) lds_read16<S0>(wq[0][wi], taddr[0][wi]);
+      lds_read16<P0>(pq[0], paddr_c);
+      static_for<0, Cfg::QPL>([&](auto QQ) {
+        constexpr int qq = decltype(QQ)::value;
+        constexpr int cur = qq & 1;
+        uint32_t s1, s2, e1, o1, e2, o2, ua[8];
+        float va[8], vb[8];
+        lds_wait<0>();                                          // this quad's words and probabilities
+        // token 0
+        tri_streams(s1, s2, wq[cur][0].x, wq[cur][1].x, wq[cur][2].x, hf);
+        tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
+        tri_extract_a(ua, e1, o1); lut_read8<L0 + (qq * 4 + 0) * TS>(va, ua);
+        tri_extract_b(ua, e1, o1, e2, o2); lut_read8<L0 + (qq * 4 + 0) * TS>(vb, ua);
+        if (more && spread) issue_fast<BITS, qq>(a, df, lds0, 1 - stage, pnext, FUSED ? a.scores : a.p, cn0, pc0, row_base, h0, b);
+        // token 1
+        tri_streams(s1, s2, wq[cur][0].y, wq[cur][1].y, wq[cur][2].y, hf);
+        tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
+        lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].x);
+        tri_extract_a(ua, e1, o1); lut_read8<L0 + (qq * 4 + 1) * TS>(va, ua);
+        lds_wait<8>(); fmac8_at<8>(acc, vb, pq[cur].x);
+        tri_extract_b(ua, e1, o1, e2, o2); lut_read8<L0 + (qq * 4 + 1) * TS>(vb, ua);
+        // token 2
+        tri_streams(s1, s2, wq[cur][0].z, wq[cur][1].z, wq[cur][2].z, hf);
+        tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
+        lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].y);
+        tri_extract_a(ua, e1, o1); lut_read8<L0 + (qq * 4 + 2) * TS>(va, ua);
+        lds_wait<8>(); fmac8_at<8>(acc, vb, pq[cur].y);
+        tri_extract_b(ua, e1, o1, e2, o2); lut_read8<L0 + (qq * 4 + 2) * TS>(vb, ua);
+        // token 3
+        tri_streams(s1, s2, wq[cur][0].w, wq[cur][1].w, wq[cur][2].w, hf);
+        tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
+        lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].z);
+        tri_extract_a(ua, e1, o1); lut_read8<L0 + (qq * 4 + 3) * TS>(va, ua);
+        lds_wait<8>(); fmac8_at<8>(acc, vb, pq[cur].z);
+        tri_extract_b(ua, e1, o1, e2, o2); lut_read8<L0 + (qq * 4 + 3) * TS>(vb, ua);
+        if constexpr (qq + 1 < Cfg::QPL) {                      // the next quad, behind the look-ups in flight
+#pragma unroll
+          for (int wi = 0; wi < 3; wi++) lds_read16<S0>(wq[1 - cur][wi], taddr[qq + 1][wi]);
+          lds_read16<P0 + (qq + 1) * 16>(pq[1 - cur], paddr_c);
+          lds_wait<12>(); fmac8_at<0>(acc, va, pq[cur].w);
+          lds_wait<4>(); fmac8_at<8>(acc, vb, pq[cur].w);
+        } else {
+          lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].w);
+          lds_wait<0>(); fmac8_at<8>(acc, vb, pq[cur].w);
         }
       });
 #if KVQ_TRACE
