@@ -6,6 +6,7 @@
 //   MODE 1: per 2 tokens: prep x2, extract x2, 16 reads... (lgkmcnt saturates at 15) (16 in flight)
 //   MODE 2: pipelined: token t+1's prep/extract/reads are issued before token t's FMAs (wait lgkmcnt(8))
 //   MODE 3: as 2 + the probabilities of the quad from LDS (ds_read_b128, broadcast) instead of a register
+//   MODE 4: as 2, the quad as one asm block with the look-up results in pinned register pairs and v_pk_fma_f32
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -29,6 +30,8 @@
                "v_fmac_f32 %4, %12, %16\n v_fmac_f32 %5, %13, %16\n v_fmac_f32 %6, %14, %16\n v_fmac_f32 %7, %15, %16\n" \
                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])       \
                : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(p))
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define QUAD_ASM "s_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 v100, 2, %[wx]\n\tv_lshrrev_b32 v101, 2, %[wx]\n\tv_and_or_b32 v100, v100, %[mask], %[slot]\n\tv_and_or_b32 v101, v101, %[mask], %[slot]\n\tv_and_b32 v102, 0xff, v100\n\tv_and_b32 v103, 0xff, v101\n\tv_bfe_u32 v104, v100, 8, 8\n\tv_bfe_u32 v105, v101, 8, 8\n\tv_bfe_u32 v106, v100, 16, 8\n\tv_bfe_u32 v107, v101, 16, 8\n\tv_lshrrev_b32 v108, 24, v100\n\tv_lshrrev_b32 v109, 24, v101\n\tds_read_b32 v110, v102 offset:0\n\tds_read_b32 v111, v103 offset:0\n\tds_read_b32 v112, v104 offset:0\n\tds_read_b32 v113, v105 offset:0\n\tds_read_b32 v114, v106 offset:0\n\tds_read_b32 v115, v107 offset:0\n\tds_read_b32 v116, v108 offset:0\n\tds_read_b32 v117, v109 offset:0\n\tv_lshlrev_b32 v100, 2, %[wy]\n\tv_lshrrev_b32 v101, 2, %[wy]\n\tv_and_or_b32 v100, v100, %[mask], %[slot]\n\tv_and_or_b32 v101, v101, %[mask], %[slot]\n\tv_and_b32 v102, 0xff, v100\n\tv_and_b32 v103, 0xff, v101\n\tv_bfe_u32 v104, v100, 8, 8\n\tv_bfe_u32 v105, v101, 8, 8\n\tv_bfe_u32 v106, v100, 16, 8\n\tv_bfe_u32 v107, v101, 16, 8\n\tv_lshrrev_b32 v108, 24, v100\n\tv_lshrrev_b32 v109, 24, v101\n\tds_read_b32 v118, v102 offset:128\n\tds_read_b32 v119, v103 offset:128\n\tds_read_b32 v120, v104 offset:128\n\tds_read_b32 v121, v105 offset:128\n\tds_read_b32 v122, v106 offset:128\n\tds_read_b32 v123, v107 offset:128\n\tds_read_b32 v124, v108 offset:128\n\tds_read_b32 v125, v109 offset:128\n\ts_waitcnt lgkmcnt(8)\n\tv_pk_fma_f32 %[a0], v[110:111], %[pxy], %[a0] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a1], v[112:113], %[pxy], %[a1] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a2], v[114:115], %[pxy], %[a2] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a3], v[116:117], %[pxy], %[a3] op_sel_hi:[1,0,1]\n\tv_lshlrev_b32 v100, 2, %[wz]\n\tv_lshrrev_b32 v101, 2, %[wz]\n\tv_and_or_b32 v100, v100, %[mask], %[slot]\n\tv_and_or_b32 v101, v101, %[mask], %[slot]\n\tv_and_b32 v102, 0xff, v100\n\tv_and_b32 v103, 0xff, v101\n\tv_bfe_u32 v104, v100, 8, 8\n\tv_bfe_u32 v105, v101, 8, 8\n\tv_bfe_u32 v106, v100, 16, 8\n\tv_bfe_u32 v107, v101, 16, 8\n\tv_lshrrev_b32 v108, 24, v100\n\tv_lshrrev_b32 v109, 24, v101\n\tds_read_b32 v110, v102 offset:256\n\tds_read_b32 v111, v103 offset:256\n\tds_read_b32 v112, v104 offset:256\n\tds_read_b32 v113, v105 offset:256\n\tds_read_b32 v114, v106 offset:256\n\tds_read_b32 v115, v107 offset:256\n\tds_read_b32 v116, v108 offset:256\n\tds_read_b32 v117, v109 offset:256\n\ts_waitcnt lgkmcnt(8)\n\tv_pk_fma_f32 %[a0], v[118:119], %[pxy], %[a0] op_sel:[0,1,0]\n\tv_pk_fma_f32 %[a1], v[120:121], %[pxy], %[a1] op_sel:[0,1,0]\n\tv_pk_fma_f32 %[a2], v[122:123], %[pxy], %[a2] op_sel:[0,1,0]\n\tv_pk_fma_f32 %[a3], v[124:125], %[pxy], %[a3] op_sel:[0,1,0]\n\tv_lshlrev_b32 v100, 2, %[ww]\n\tv_lshrrev_b32 v101, 2, %[ww]\n\tv_and_or_b32 v100, v100, %[mask], %[slot]\n\tv_and_or_b32 v101, v101, %[mask], %[slot]\n\tv_and_b32 v102, 0xff, v100\n\tv_and_b32 v103, 0xff, v101\n\tv_bfe_u32 v104, v100, 8, 8\n\tv_bfe_u32 v105, v101, 8, 8\n\tv_bfe_u32 v106, v100, 16, 8\n\tv_bfe_u32 v107, v101, 16, 8\n\tv_lshrrev_b32 v108, 24, v100\n\tv_lshrrev_b32 v109, 24, v101\n\tds_read_b32 v118, v102 offset:384\n\tds_read_b32 v119, v103 offset:384\n\tds_read_b32 v120, v104 offset:384\n\tds_read_b32 v121, v105 offset:384\n\tds_read_b32 v122, v106 offset:384\n\tds_read_b32 v123, v107 offset:384\n\tds_read_b32 v124, v108 offset:384\n\tds_read_b32 v125, v109 offset:384\n\ts_waitcnt lgkmcnt(8)\n\tv_pk_fma_f32 %[a0], v[110:111], %[pzw], %[a0] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a1], v[112:113], %[pzw], %[a1] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a2], v[114:115], %[pzw], %[a2] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a3], v[116:117], %[pzw], %[a3] op_sel_hi:[1,0,1]\n\ts_waitcnt lgkmcnt(0)\n\tv_pk_fma_f32 %[a0], v[118:119], %[pzw], %[a0] op_sel:[0,1,0]\n\tv_pk_fma_f32 %[a1], v[120:121], %[pzw], %[a1] op_sel:[0,1,0]\n\tv_pk_fma_f32 %[a2], v[122:123], %[pzw], %[a2] op_sel:[0,1,0]\n\tv_pk_fma_f32 %[a3], v[124:125], %[pzw], %[a3] op_sel:[0,1,0]"
 #define WAIT(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory")
 
 template <int MODE>
@@ -41,6 +44,7 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
   if (threadIdx.x < 512) pbuf[threadIdx.x] = 0.001f * threadIdx.x;
   __syncthreads();
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x2 a2[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
   const unsigned slot = ((threadIdx.x >> 8) & 1) * 0x40404040u;
   const unsigned tbase = (unsigned)(uintptr_t)tile + (threadIdx.x & 255) * 128;   // 8 quads per lane
   const unsigned pbase = (unsigned)(uintptr_t)pbuf + ((threadIdx.x >> 4) & 15) * 128;
@@ -70,6 +74,16 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
       PREP(we, wo, w.z, slot); EXTRACT(u, we, wo); READ8(v, u, 256);
       PREP(we, wo, w.w, slot); EXTRACT(u2, we, wo); READ8(v2, u2, 384);
       WAIT(8); FMA8(a, v, p4.z); WAIT(0); FMA8(a, v2, p4.w);
+    } else if (MODE == 4) {
+      // the whole quad as ONE instruction block: pinned temporaries (v100-v125), look-up results in even-aligned register
+      // pairs, v_pk_fma_f32 (two channels per instruction, full rate) instead of v_fmac
+      f32x2 pxy = {p4.x, p4.y}, pzw = {p4.z, p4.w};
+      asm volatile(QUAD_ASM
+                   : [a0] "+v"(a2[0]), [a1] "+v"(a2[1]), [a2] "+v"(a2[2]), [a3] "+v"(a2[3])
+                   : [wx] "v"(w.x), [wy] "v"(w.y), [wz] "v"(w.z), [ww] "v"(w.w), [pxy] "v"(pxy), [pzw] "v"(pzw), [slot] "v"(slot),
+                     [mask] "s"(0x3C3C3C3Cu)
+                   : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+                     "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125");
     } else {
       PREP(we, wo, w.x, slot); EXTRACT(u, we, wo); READ8(v, u, 0);
       PREP(we, wo, w.y, slot); EXTRACT(u2, we, wo); READ8(v2, u2, 128);
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
       WAIT(0); FMA8(a, v2, p4.w);
     }
   }
-  float s = a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7];
+  float s = a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7] + a2[0].x + a2[0].y + a2[1].x + a2[1].y + a2[2].x + a2[2].y + a2[3].x + a2[3].y;
   if (s == 12345.678f) out[0] = s;
 }
 
@@ -108,5 +122,6 @@ int main() {
   RUN(1, "quad loop, 16 in flight")
   RUN(2, "quad loop, software pipelined (reads of t+1 before FMAs of t)")
   RUN(3, "as above + probabilities from LDS")
+  RUN(4, "one asm block per quad, v_pk_fma_f32 on pinned pairs")
   return 0;
 }
