@@ -351,6 +351,27 @@ __device__ __forceinline__ void lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- 2 bit: a word holds 16 codes; pre-masked word k holds code*4 (+ the slot's row offset, 16 bytes) of channel
+// 4b + k in byte b, so one byte extraction per code is its look-up address
+__device__ __forceinline__ void duo_prep(uint32_t (&pk)[4], uint32_t w, uint32_t slotpat) {
+  asm volatile("v_lshlrev_b32 %0, 2, %4\n\tv_lshrrev_b32 %2, 2, %4\n\tv_lshrrev_b32 %3, 4, %4\n\t"
+               "v_and_or_b32 %0, %0, %5, %6\n\tv_and_or_b32 %1, %4, %5, %6\n\tv_and_or_b32 %2, %2, %5, %6\n\tv_and_or_b32 %3, %3, %5, %6"
+               : "=&v"(pk[0]), "=&v"(pk[1]), "=&v"(pk[2]), "=&v"(pk[3]) : "v"(w), "s"(0x0C0C0C0Cu), "v"(slotpat));
+}
+// channels 0..7 (bytes 0 and 1 of the four pre-masked words) / 8..15 (bytes 2 and 3)
+__device__ __forceinline__ void duo_extract_a(uint32_t (&u)[8], const uint32_t (&pk)[4]) {
+  asm volatile("v_and_b32 %0, 0xff, %8\n\tv_and_b32 %1, 0xff, %9\n\tv_and_b32 %2, 0xff, %10\n\tv_and_b32 %3, 0xff, %11\n\t"
+               "v_bfe_u32 %4, %8, 8, 8\n\tv_bfe_u32 %5, %9, 8, 8\n\tv_bfe_u32 %6, %10, 8, 8\n\tv_bfe_u32 %7, %11, 8, 8"
+               : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+               : "v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]));
+}
+__device__ __forceinline__ void duo_extract_b(uint32_t (&u)[8], const uint32_t (&pk)[4]) {
+  asm volatile("v_bfe_u32 %0, %8, 16, 8\n\tv_bfe_u32 %1, %9, 16, 8\n\tv_bfe_u32 %2, %10, 16, 8\n\tv_bfe_u32 %3, %11, 16, 8\n\t"
+               "v_lshrrev_b32 %4, 24, %8\n\tv_lshrrev_b32 %5, 24, %9\n\tv_lshrrev_b32 %6, 24, %10\n\tv_lshrrev_b32 %7, 24, %11"
+               : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+               : "v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]));
+}
+
 // ---- 3 bit: the 32 codes of a unit are one 96-bit stream over three words; a lane decodes 16 of them (its half).
 // `src` holds consecutive 3-bit codes from bit 0: the even ones masked in place and shifted left by 2, the odd ones
 // shifted right by 1 and masked, land as code*4 in bits [6j+2, 6j+5) of 6-bit fields -- bit 6j+5 takes the slot's table
@@ -614,7 +635,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   const uint32_t slotpat = (uint32_t)sl * 0x40404040u;
 
   // hand-scheduled loops (3 / 4 bit): the lane's LDS addresses inside a stage do not change with the chunk
-  constexpr bool ASM_LOOP = (BITS == 4 || BITS == 3) && KVQ_V_ASM;
+  constexpr bool ASM_LOOP = KVQ_V_ASM;
   uint32_t taddr[Cfg::QPL][WORDS];   // its 16-byte quads of the tile
   uint32_t paddr = 0;                // the probabilities of its head for its slot's tokens
   if constexpr (ASM_LOOP) {
@@ -780,6 +801,58 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
           lds_read16<P0 + (qq + 1) * 16>(pq[1 - cur], paddr_c);
           lds_wait<12>(); fmac8_at<0>(acc, va, pq[cur].w);
           lds_wait<4>(); fmac8_at<8>(acc, vb, pq[cur].w);
+        } else {
+          lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].w);
+          lds_wait<0>(); fmac8_at<8>(acc, vb, pq[cur].w);
+        }
+      });
+#if KVQ_TRACE
+      stamp(4);
+#endif
+      return;
+    }
+    if constexpr (BITS == 2 && KVQ_V_ASM) {
+      // as the 3-bit loop: two groups of 8 look-ups per token (channels 0..7 and 8..15 of the word)
+      constexpr int S0 = Cfg::tile_off(stage);
+      constexpr int L0 = Cfg::lut_off(stage);
+      constexpr int P0 = Cfg::p_off(0);
+      constexpr int TS = Cfg::SLOTS * N * 4;
+      const uint32_t paddr_c = paddr + (uint32_t)(pcur * Cfg::P_B);
+      const uint32_t slot2 = (uint32_t)sl * 0x10101010u;        // the slot's row offset (N*4 = 16 bytes) in every byte
+      uint4 wq[2];
+      float4 pq[2];
+      lds_read16<S0>(wq[0], taddr[0][0]);
+      lds_read16<P0>(pq[0], paddr_c);
+      static_for<0, Cfg::QPL>([&](auto QQ) {
+        constexpr int qq = decltype(QQ)::value;
+        constexpr int cur = qq & 1;
+        uint32_t pk[4], ua[8];
+        float va[8], vb[8];
+        lds_wait<0>();
+        duo_prep(pk, wq[cur].x, slot2);
+        duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 0) * TS>(va, ua);
+        duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 0) * TS>(vb, ua);
+        if (more && spread) issue_fast<BITS, qq>(a, df, lds0, 1 - stage, pnext, FUSED ? a.scores : a.p, cn0, pc0, row_base, h0, b);
+        duo_prep(pk, wq[cur].y, slot2);
+        lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].x);
+        duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 1) * TS>(va, ua);
+        lds_wait<8>(); fmac8_at<8>(acc, vb, pq[cur].x);
+        duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 1) * TS>(vb, ua);
+        duo_prep(pk, wq[cur].z, slot2);
+        lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].y);
+        duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 2) * TS>(va, ua);
+        lds_wait<8>(); fmac8_at<8>(acc, vb, pq[cur].y);
+        duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 2) * TS>(vb, ua);
+        duo_prep(pk, wq[cur].w, slot2);
+        lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].z);
+        duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 3) * TS>(va, ua);
+        lds_wait<8>(); fmac8_at<8>(acc, vb, pq[cur].z);
+        duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 3) * TS>(vb, ua);
+        if constexpr (qq + 1 < Cfg::QPL) {
+          lds_read16<S0>(wq[1 - cur], taddr[qq + 1][0]);
+          lds_read16<P0 + (qq + 1) * 16>(pq[1 - cur], paddr_c);
+          lds_wait<10>(); fmac8_at<0>(acc, va, pq[cur].w);
+          lds_wait<2>(); fmac8_at<8>(acc, vb, pq[cur].w);
         } else {
           lds_wait<8>(); fmac8_at<0>(acc, va, pq[cur].w);
           lds_wait<0>(); fmac8_at<8>(acc, vb, pq[cur].w);
