@@ -449,7 +449,17 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 
   const uint32_t lds0 = lds_addr(smem);
   const DmaLane dl = make_dma_lane<BITS>();
-  issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
+  const bool sparse = (a.outliers != nullptr) && (b == 0);   // reference: batch 0 only (KCU:3675)
+  // The sparse phase is bound by memory latency (VALU and LDS idle), the dense loop by the LDS pipe.  Half of the
+  // workgroups run it BEFORE their dense loop, the other half after it: wherever two workgroups share a CU in either
+  // order, one's latency-bound phase hides behind the other's look-ups (all of them at the end: 19 % of the kernel
+  // with nothing to overlap; all of them at the start: every workgroup stalls at once).
+#ifndef KVQ_V_SPFIRST
+#define KVQ_V_SPFIRST 1   // 0: always after the loop; 1: odd workgroups first; 2: the second half of the grid first
+#endif
+  const bool sparse_first = !FUSED && sparse &&
+                            (KVQ_V_SPFIRST == 1 ? (blockIdx.x & 1) : (KVQ_V_SPFIRST == 2 ? (blockIdx.x >= gridDim.x / 2) : 0));
+  if (!sparse_first) issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
   const float2 *mz = reinterpret_cast<const float2 *>(smem + Cfg::SMEM_B);   // FUSED: (max, normaliser) per head
   float myM = 0.f, myZ = 1.f;                                                  // ... of the head this lane converts for
   if constexpr (FUSED) {
@@ -491,10 +501,6 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   // (measured, tools/ubench/lds_atomic.hip).  The accumulator sits behind pipeline stage 0, idle until
   // the first chunk iteration; the sums go to this workgroup's own sparse slab, which the reduce kernel
   // adds like any other slab.
-  const bool sparse = (a.outliers != nullptr) && (b == 0);   // reference: batch 0 only (KCU:3675)
-  // The sparse phase is bound by memory latency (VALU idle), the dense loop by VALU issue; run AFTER the
-  // dense loop it fills the ragged end of the grid (workgroups finish their dense part at different
-  // times) instead of stalling every workgroup at once at the start of the kernel (103 -> 97 us at 128K).
 #if KVQ_TRACE
   unsigned tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned tr_prev;
@@ -617,6 +623,11 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       __syncthreads();   // (frees the accumulators for the next pass)
     }
     };
+  if (sparse_first) {
+    sparse_phase();
+    __syncthreads();                      // the phase is done with the LDS: the first chunk may land
+    issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
+  }
   constexpr int CHL = Cfg::CHL;
   float acc[CHL];
 #pragma unroll
@@ -974,7 +985,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     tr_prev = (unsigned)tt;
   }
 #endif
-  if (sparse) {
+  if (sparse && !sparse_first) {
     __syncthreads();   // the slot reduction is done with the LDS
     sparse_phase();
   }
