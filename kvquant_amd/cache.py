@@ -17,6 +17,8 @@ work unchanged.  What changed underneath:
 There is no CPU fallback: the tensors live on a GPU and every op raises if the
 HIP library is missing.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -507,6 +509,8 @@ class QuantV(nn.Module):
 
 
 FUSE_SOFTMAX_INTO_MIX_V = False
+# ... except for short caches, where a launch less is worth more than the second conversion (env: A/B runs)
+FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", "32768"))
 
 
 def decode_kv(kc, vc, q, k, v, sink_scores=None):
@@ -537,7 +541,7 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     H = kc.num_heads
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
     out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
-    if FUSE_SOFTMAX_INTO_MIX_V:
+    if FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO:
         sink_probs = ops.score_k_mix_v(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
                                        kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), vc.vcache, out,
                                        vc.mix_table(), vc.outliers, vc.outlier_indices, sink_scores, kc.outliers_t,

@@ -132,7 +132,13 @@ struct MixArgs {
   // FUSED softmax (decode, q_len = 1): `p` is unused; the kernel reads the RAW scores and converts them to
   // probabilities on the way (exactly the arithmetic of kvq_softmax_finish: half(expf(half(half(s) * inv) - M) / Z))
   const float *scores;     // [H][L]
-  const float *mz;         // [H][2]: (max, normaliser) of every row, merged from the partials by softmax_merge_kernel
+  const float *mz;         // [H][2]: (max, normaliser) of every row, merged from the partials by softmax_merge_kernel,
+                           // or null: few partials (short caches), every workgroup merges them itself (one launch less)
+  const float *parts;      // [H][n_parts][2]
+  int n_parts;
+  const __half *sink;      // [H][n_sink] or null
+  __half *sink_probs;
+  int n_sink;
   float inv;
 #if KVQ_TRACE
   unsigned long long *trace;   // development: [block][wave][chunk][8]
@@ -468,19 +474,57 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     if (n_chunks > 1) issue_p<BITS>(a.scores, a, dl, lds0 + Cfg::p_off(1), t0 + CT, h0, b);
     // (max, normaliser) of every head -> LDS (the sparse phase needs all of them), this lane's head -> registers
     float2 *mzw = reinterpret_cast<float2 *>(smem + Cfg::SMEM_B);
-    for (int h = tid; h < a.H; h += Cfg::NT) {
-      const float2 t = reinterpret_cast<const float2 *>(a.mz)[h];
-      mzw[h] = make_float2(t.x, 1.0f / t.y);     // (max, 1 / normaliser)
-    }
-    {
-      const int hr = tid / CT;                       // the element of a p buffer this lane converts: [hr][tid % CT]
-      const int hc = h0 + hr < a.H ? h0 + hr : a.H - 1;
-      const float2 t = reinterpret_cast<const float2 *>(a.mz)[hc];
-      myM = t.x;
-      myZ = 1.0f / t.y;
+    if (a.mz != nullptr) {
+      for (int h = tid; h < a.H; h += Cfg::NT) {
+        const float2 t = reinterpret_cast<const float2 *>(a.mz)[h];
+        mzw[h] = make_float2(t.x, 1.0f / t.y);     // (max, 1 / normaliser)
+      }
+    } else {
+      // few partials: 16 lanes per head merge them (+ the fp16 sink scores) here, the same way in every workgroup
+      const int sub = tid & 15;
+      for (int hb = 0; hb < a.H; hb += Cfg::NT / 16) {
+        const int h = hb + (tid >> 4);
+        const bool hv = h < a.H;
+        const float2 *pr = reinterpret_cast<const float2 *>(a.parts) + (int64_t)(hv ? h : 0) * a.n_parts;
+        float M = -INFINITY, Z = 0.f;
+        for (int i = sub; i < a.n_parts; i += 16) {
+          const float2 ms = hv ? pr[i] : make_float2(-INFINITY, 0.f);
+          if (ms.x > -INFINITY) {
+            const float mn = fmaxf(M, ms.x);
+            Z = Z * mz_w(M - mn) + ms.y * mz_w(ms.x - mn);
+            M = mn;
+          }
+        }
+        if (hv)
+          for (int i = sub; i < a.n_sink; i += 16) {
+            const float x = __half2float(a.sink[h * a.n_sink + i]);
+            const float mn = fmaxf(M, x);
+            Z = Z * expf(M - mn) + expf(x - mn);
+            M = mn;
+          }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+          const float mo = __shfl_xor(M, d), zo = __shfl_xor(Z, d);
+          const float mn = fmaxf(M, mo);
+          Z = (mn == -INFINITY) ? 0.f : Z * mz_w(M - mn) + zo * mz_w(mo - mn);
+          M = mn;
+        }
+        if (hv && sub == 0) mzw[h] = make_float2(M, 1.0f / Z);
+      }
     }
     dma_wait_all();
     __syncthreads();          // mz visible, the scores of chunk 0 (and 1) landed
+    {
+      const int hr = tid / CT;                       // the element of a p buffer this lane converts: [hr][tid % CT]
+      const int hc = h0 + hr < a.H ? h0 + hr : a.H - 1;
+      myM = mz[hc].x;
+      myZ = mz[hc].y;
+    }
+    if (a.mz == nullptr && blockIdx.x == 0 && a.n_sink > 0)
+      for (int i = tid; i < a.H * a.n_sink; i += Cfg::NT) {
+        const float2 t = mz[i / a.n_sink];
+        a.sink_probs[i] = __float2half_rn(prob_fp16(__half2float(a.sink[i]), t.x, t.y));
+      }
   }
   // FUSED: raw score -> probability in place, one element per lane; tokens at or past the end of the range get 0
   auto convert_p = [&](int pbuf, int64_t c0) {
@@ -1123,6 +1167,8 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   return pl;
 }
 
+constexpr int kMergeInKernelParts = 128;   // up to 32K cached tokens: the p.V workgroups merge the softmax partials themselves
+
 struct FusedSoftmax {
   const float *scores, *parts;
   int n_parts;
@@ -1142,13 +1188,21 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   a.sparse_partial = a.partial + (size_t)pl.n_ranges * a.q_len * a.H * kHeadDim;
   dim3 grid(pl.n_ranges * pl.groups, 1, a.q_len), block(Cfg::NT);
   if (fs) {
-    float *mz = a.sparse_partial + (size_t)pl.n_ranges * pl.groups * a.H * kHeadDim;   // (tail of the workspace)
-    softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz);
-    int rc0 = check_launch();
-    if (rc0) return rc0;
     a.scores = fs->scores;
-    a.mz = mz;
     a.inv = fs->inv;
+    a.parts = fs->parts;
+    a.n_parts = fs->n_parts;
+    a.sink = fs->sink;
+    a.sink_probs = fs->sink_probs;
+    a.n_sink = fs->n_sink;
+    a.mz = nullptr;
+    if (fs->n_parts > kMergeInKernelParts) {
+      float *mz = a.sparse_partial + (size_t)pl.n_ranges * pl.groups * a.H * kHeadDim;   // (tail of the workspace)
+      softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz);
+      int rc0 = check_launch();
+      if (rc0) return rc0;
+      a.mz = mz;
+    }
     mix_v_kernel<BITS, true><<<grid, block, 0, st>>>(a);
   } else {
     mix_v_kernel<BITS, false><<<grid, block, 0, st>>>(a);
@@ -1247,6 +1301,11 @@ static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.scores = nullptr;
   a.mz = nullptr;
+  a.parts = nullptr;
+  a.n_parts = 0;
+  a.sink = nullptr;
+  a.sink_probs = nullptr;
+  a.n_sink = 0;
   a.inv = 0.f;
 #if KVQ_TRACE
   a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
