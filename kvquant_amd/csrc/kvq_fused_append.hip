@@ -14,6 +14,8 @@
 #include "kvq_host.h"
 #include "kvq_ktab.h"
 
+#include <cstdlib>
+
 namespace kvq {
 
 constexpr int kSelThreads = 1024;
@@ -27,24 +29,34 @@ __device__ __forceinline__ uint32_t fkey(float x) {  // ascending order-preservi
 
 template <int NT, int E>
 struct SelShared {
-  uint32_t hist[2][256];
+  // [pass parity][side][copy][digit]: the next pass's histogram is zeroed during this pass's scan; lanes spread over
+  // HC copies of a histogram (same-address LDS atomics serialise: the first pass puts 4096 elements into ~10 bins)
+  static constexpr int HC = NT >= 1024 ? 4 : 1;
+  uint32_t hist[2][2][HC][256];
   uint32_t wsum[NT / 64 + 1];
   uint32_t prefix[2];
   uint32_t krem[2];
   uint32_t scan[NT / 64];
-  unsigned codes[E * NT];
+  unsigned codes[E * NT + E * NT / 32];   // channel c at c + c/32: the pack's lane-per-group reads are conflict free
 };
+
+// inclusive prefix sum over the 64 lanes of a wave with DPP row operations: six dependent VALU instructions instead of
+// six ds_bpermute round trips (the select is a chain of latencies: four passes x (atomics, barrier, scan, barrier))
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
 
 // exclusive block scan of one uint per lane (wave shuffles + LDS across waves)
 template <int NT>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, uint32_t &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t o = __shfl_up(inc, d);
-    if (lane >= d) inc += o;
-  }
+  const uint32_t inc = wave_incl_scan(v);
   __syncthreads();
   if (lane == 63) ws[wave] = inc;
   __syncthreads();
@@ -70,12 +82,12 @@ __device__ __forceinline__ void radix_select_both(const uint32_t (&key)[E], cons
     sh.prefix[tid] = 0;
     sh.krem[tid] = k;
   }
+  constexpr int HC = SelShared<NT, E>::HC;
+  for (int i = tid; i < 512 * HC; i += NT) (&sh.hist[1][0][0][0])[i] = 0;   // (the first pass is pass 3: parity 1)
+  __syncthreads();
   for (int pass = 3; pass >= 0; pass--) {
-    if (tid < 256) {
-      sh.hist[0][tid] = 0;
-      sh.hist[1][tid] = 0;
-    }
-    __syncthreads();
+    uint32_t (*hist)[HC][256] = sh.hist[pass & 1];
+    const int cp = tid & (HC - 1);
     const uint32_t p0 = sh.prefix[0], p1 = sh.prefix[1];
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -85,11 +97,12 @@ __device__ __forceinline__ void radix_select_both(const uint32_t (&key)[E], cons
       const uint32_t d = (kk >> (8 * pass)) & 0xffu;
       // (the LDS atomics are what bounds the prefill pack -- 8 tokens per CU histogram at once; in the first pass
       //  both sides count every element, so they share one histogram: 40 % fewer atomics over the four passes)
-      if (hi == p0) atomicAdd(&sh.hist[0][d], 1u);
-      if (pass != 3 && hi == p1) atomicAdd(&sh.hist[1][d], 1u);
+      if (hi == p0) atomicAdd(&hist[0][cp][d], 1u);
+      if (pass != 3 && hi == p1) atomicAdd(&hist[1][cp][d], 1u);
     }
     __syncthreads();
-    // wave 0 resolves the "largest" side (scan bins downward), wave 1 the "smallest" side (upward)
+    // wave 0 resolves the "largest" side (scan bins downward), wave 1 the "smallest" side (upward); the other
+    // lanes zero the next pass's histogram meanwhile (two barriers per pass instead of three)
     const int wave = tid >> 6, lane = tid & 63;
     if (wave < 2) {
       const int side = wave;
@@ -100,15 +113,12 @@ __device__ __forceinline__ void radix_select_both(const uint32_t (&key)[E], cons
       for (int j = 0; j < 4; j++) {
         const int pos = lane * 4 + j;                      // position in scan order
         const int bin = side == 0 ? 255 - pos : pos;
-        c[j] = sh.hist[pass == 3 ? 0 : side][bin];
+        c[j] = 0;
+#pragma unroll
+        for (int q = 0; q < HC; q++) c[j] += hist[pass == 3 ? 0 : side][q][bin];
         s += c[j];
       }
-      uint32_t inc = s;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-      }
+      const uint32_t inc = wave_incl_scan(s);
       const uint32_t before = inc - s;                     // elements in bins scanned before this lane's
       const uint32_t kr = sh.krem[side];
       if (before < kr && kr <= inc) {                      // the k-th element is in one of my 4 bins
@@ -124,6 +134,8 @@ __device__ __forceinline__ void radix_select_both(const uint32_t (&key)[E], cons
           run += c[j];
         }
       }
+    } else if (pass > 0) {
+      for (int i = tid - 128; i < 512 * HC; i += NT - 128) (&sh.hist[(pass - 1) & 1][0][0][0])[i] = 0;
     }
     __syncthreads();
   }
@@ -159,7 +171,26 @@ struct AppendArgs {
   int C;
   int64_t max_len;
   int64_t col;
+#if KVQ_TRACE
+  unsigned long long *trace;   // development: [16] phase stamps of lane 0 (tools/dbg/trace_prologue.py)
+#endif
 };
+
+#ifndef KVQ_TRACE
+#define KVQ_TRACE 0
+#endif
+#if KVQ_TRACE
+#define KVQ_STAMP(A, k)                                                                         \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && (A).trace) {                                                        \
+      unsigned long long tt;                                                                    \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");           \
+      (A).trace[k] = tt;                                                                        \
+    }                                                                                           \
+  } while (0)
+#else
+#define KVQ_STAMP(A, k)
+#endif
 
 // K: rescaled selection, per-channel LUT; V: raw selection, per-token LUT row built here.
 // Executed by one whole workgroup of NT lanes (NT = 1024: the decode append, one latency-critical workgroup;
@@ -188,6 +219,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   float xv[E], sel[E];
   uint32_t key[E];
   bool ok[E];
+  KVQ_STAMP(A, 0);
 #pragma unroll
   for (int e = 0; e < E; e++) {
     ok[e] = e < per && (c0 + e) < C;
@@ -234,7 +266,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
         const float4 t = *reinterpret_cast<const float4 *>(src + v);
         row[v] = t.x; row[v + 1] = t.y; row[v + 2] = t.z; row[v + 3] = t.w;
       }
-      sh.codes[c0 + e] = nearest_code<N>(row, xv[e]);
+      sh.codes[(c0 + e) + ((c0 + e) >> 5)] = nearest_code<N>(row, xv[e]);
       if (!pre_ends) {
         end_lo[e] = row[0];
         end_hi[e] = row[N - 1];
@@ -244,21 +276,38 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
 
   uint32_t T[2], gt[2];
   const uint32_t ksel = IS_V ? (uint32_t)(thr_k + 1) : (uint32_t)thr_k;   // V: threshold is the (thr_k+1)-th
+  asm volatile("" :: "v"(key[0]), "v"(end_lo[0]));
+  KVQ_STAMP(A, 1);
   radix_select_both<NT, E>(key, ok, ksel, sh, T, gt);
+  KVQ_STAMP(A, 2);
 
   // ---- membership: strictly beyond the threshold, plus the first ties in channel order ----------
   // K keeps k = thr_k per side; V keeps the top thr_k of the thr_k+1 selected (the last-ranked one,
   // i.e. the highest-index tie, is the clipping threshold itself: modeling_llama.py:1091-1096).
-  uint32_t ntie_hi = 0, ntie_lo = 0;
-#pragma unroll
-  for (int e = 0; e < E; e++) {
-    if (!ok[e]) continue;
-    ntie_hi += key[e] == T[0];
-    ntie_lo += key[e] == T[1];
+  // (the last radix pass left the number of elements equal to each threshold in its histogram: when it is exactly
+  //  the number still wanted, or none is wanted -- no run of ties is cut, the usual case -- the ranks are not needed
+  //  and the block scan is skipped)
+  uint32_t eq_hi = 0, eq_lo = 0;                                        // (pass 0: parity 0)
+  for (int q = 0; q < SelShared<NT, E>::HC; q++) {
+    eq_hi += sh.hist[0][0][q][T[0] & 0xffu];
+    eq_lo += sh.hist[0][1][q][T[1] & 0xffu];
   }
-  uint32_t tot;
-  const uint32_t packed = block_excl_scan<NT>(ntie_hi | (ntie_lo << 16), sh.scan, tot);
-  uint32_t rank_hi = packed & 0xffffu, rank_lo = packed >> 16;
+  const uint32_t w_hi = (uint32_t)thr_k - gt[0], w_lo = (uint32_t)thr_k - gt[1];
+  const bool cut = !((w_hi == 0 || eq_hi == w_hi) && (w_lo == 0 || eq_lo == w_lo));   // (block-uniform)
+  uint32_t rank_hi = 0, rank_lo = 0;
+  if (cut) {
+    uint32_t ntie_hi = 0, ntie_lo = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (!ok[e]) continue;
+      ntie_hi += key[e] == T[0];
+      ntie_lo += key[e] == T[1];
+    }
+    uint32_t tot;
+    const uint32_t packed = block_excl_scan<NT>(ntie_hi | (ntie_lo << 16), sh.scan, tot);
+    rank_hi = packed & 0xffffu;
+    rank_lo = packed >> 16;
+  }
   const uint32_t want_hi = (uint32_t)thr_k - gt[0], want_lo = (uint32_t)thr_k - gt[1];
   bool in_hi[E], in_lo[E];
   uint32_t nsel = 0;
@@ -273,6 +322,7 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
     nsel += (in_hi[e] || in_lo[e]);
   }
 
+  KVQ_STAMP(A, 3);
   // ---- V: thresholds, scale/offset and the per-token codebook row ---------------------------------
   float vmin = 0.f, vmax = 0.f, zp = 0.f;
   if constexpr (IS_V) {
@@ -308,10 +358,11 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
       // clipped to the zero-point code iff stored sparse (include/kvq.h: kvq_vopts); with the reference's quirk:
       // iff strictly outside the thresholds (KCU:2084), which misses a selected element that equals one of them
       const bool clip = A.tie_quirk ? (xv[e] < vmin || xv[e] > vmax) : (in_hi[e] || in_lo[e]);
-      sh.codes[c0 + e] = clip ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, xv[e]);
+      sh.codes[(c0 + e) + ((c0 + e) >> 5)] = clip ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, xv[e]);
     }
   }
 
+  KVQ_STAMP(A, 4);
   // ---- outlier row: compaction in channel order ------------------------------------------------------
   uint32_t tot2;
   uint32_t pos = block_excl_scan<NT>(nsel, sh.scan, tot2);   // (the barriers inside also publish sh.codes)
@@ -345,17 +396,19 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
     pos++;
   }
 
+  KVQ_STAMP(A, 5);
   // ---- pack: one lane per 32-channel group ------------------------------------------------------------
   if (!own_codes) return;
   for (int g = tid; g < C / 32; g += NT) {
     unsigned cd[32];
 #pragma unroll
-    for (int i = 0; i < 32; i++) cd[i] = sh.codes[g * 32 + i];
+    for (int i = 0; i < 32; i++) cd[i] = sh.codes[g * 33 + i];
     uint32_t w[BITS];
     pack32<BITS>(cd, w);
 #pragma unroll
     for (int i = 0; i < BITS; i++) mat[((int64_t)g * BITS + i) * max_len + col] = w[i];
   }
+  KVQ_STAMP(A, 6);
 }
 
 template <int BITS, bool IS_V>
@@ -472,6 +525,9 @@ static AppendArgs k_args(int32_t *mat, const float *lut, const float *lut_off, c
                          const float *lo, const float *hi, float *outliers, int32_t *idx, int thr_k, int H, int hd,
                          int64_t max_len, int64_t col, float *outliers_t = nullptr, int32_t *idx_t = nullptr) {
   AppendArgs a;
+#if KVQ_TRACE
+  a.trace = nullptr;
+#endif
   a.outliers_t = outliers_t;
   a.outlier_idx_t = idx_t;
   a.x_stride = 1;
@@ -621,6 +677,13 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
   const size_t tabb = bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
   P.q32 = reinterpret_cast<float *>(P.tab + (size_t)H * tabb);
   P.H = H;
+#if KVQ_TRACE
+  {
+    unsigned long long *tr = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
+    P.k.trace = tr;
+    P.v.trace = tr ? tr + 16 : nullptr;
+  }
+#endif
   dim3 grid(2 + H), block(kSelThreads);
   hipStream_t st = (hipStream_t)stream;
   switch (bits) {
