@@ -679,7 +679,8 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   static const int slots = workgroup_slots(score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED>, NWAVES * 64, 16 / NWAVES);
   a.groups = full_tiles ? pick_groups(a.H, full_tiles, q_len, max_hpg, slots) : 1;
   a.hpg = a.H / a.groups;
-  if (a.hpg > max_hpg) return KVQ_EINVAL;
+  if (full_tiles && a.hpg > max_hpg) return KVQ_EINVAL;   // (no full tile: only the ragged one's head groups exist)
+  if (!full_tiles && a.hpg > max_hpg) a.hpg = max_hpg;     // (unused, kept in range)
   a.full_blocks = (int)(full_tiles * a.groups);
   // ragged last tile: few heads per workgroup, so that it is a short tail rather than an extra round
 #ifndef KVQ_HPG_TAIL

@@ -10,7 +10,7 @@ from tests import util
 H, HD, C = util.H, util.HD, util.C
 
 
-def quantizer(bits, seed=0):
+def quantizer(bits, seed=0, C=C):
     g = torch.Generator().manual_seed(seed)
     scale = torch.exp(0.5 * torch.randn(C, generator=g))
     shift = 0.3 * torch.randn(C, generator=g)
@@ -20,17 +20,19 @@ def quantizer(bits, seed=0):
     return (upper, lower, [cent]), scale, shift
 
 
-def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=2e-3, norm=False):
+def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=2e-3, norm=False, heads=H):
     """prefill `prefill` tokens with parallel_pack, then `steps` decode tokens through decode_kv; returns the
-    worst relative error of the attention outputs (asserts the packed state bit for bit)."""
+    worst relative error of the attention outputs (asserts the packed state bit for bit).  heads: other model
+    widths (hidden = heads * 128; the outlier count follows the reference's int(((1 - t) / 2) * hidden) + 1)."""
     from kvquant_amd.cache import QuantK, QuantV, decode_kv
     from oracle.glue import OracleQuantK, OracleQuantV
-    quant, scale, shift = quantizer(bits, seed=bits)
+    H, C = heads, heads * HD
+    quant, scale, shift = quantizer(bits, seed=bits, C=C)
     if norm:      # (upper, lower, [centroids], normscale, normoffset), SQ:550-555
         quant = tuple(quant) + (torch.tensor(1.07), torch.tensor(-0.02))
     n = prefill + steps
     ks = util.k_tokens(n, scale, shift, seed=30 + bits)
-    vs = util.v_tokens_no_ties(n, seed=40 + bits)
+    vs = util.v_tokens_no_ties(n, Cn=C, seed=40 + bits, k=int(((1 - 0.99) / 2) * C) + 1)
     g = torch.Generator().manual_seed(50 + bits)
     qs = torch.randn(steps, H, 1, HD, generator=g).half()
     kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,

@@ -148,3 +148,13 @@ def test_v_tie_at_clip_threshold(bits):
         assert torch.equal(ref.vcache, q.vcache)
         assert torch.equal(ref.outliers[0].view(torch.int32), q.outliers[0].view(torch.int32))
     assert torch.equal(ref.lookup_table[0], q.lookup_table[0])
+
+
+@pytest.mark.parametrize("bits,heads,prefill,max_len", [(4, 40, 150, 256), (4, 8, 300, 512), (3, 40, 0, 64), (2, 16, 70, 128)])
+def test_decode_kv_other_model_widths(bits, heads, prefill, max_len):
+    """the one-call decode step at head counts other than 32 (LLaMA-13B: 40 heads, hidden 5120, 52 outlier slots;
+    narrow models): partial unit groups of the p.V kernel, head groups of the score kernel, other selection sizes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    err = decode_check.run(torch.device("cuda:0"), bits=bits, prefill=prefill, steps=3, max_len=max_len, heads=heads)
+    assert err < 2e-3

@@ -45,14 +45,18 @@ def v_tokens(S, Cn=C, seed=2):
 
 def v_tokens_no_ties(S, Cn=C, seed=2, k=21):
     """like v_tokens but without ties at the k/(k+1) selection boundary of any token: torch.topk
-    leaves the choice among equal values unspecified (the GPU selection takes the lowest channel)."""
-    while True:
-        x = v_tokens(S, Cn, seed)
+    leaves the choice among equal values unspecified (the GPU selection takes the lowest channel).
+    Tokens with such a tie are redrawn one by one (a whole-batch rejection never ends for large S x Cn)."""
+    x = v_tokens(S, Cn, seed)
+    for _ in range(1000):
         hi = torch.topk(x, k + 2, dim=-1).values
         lo = torch.topk(x, k + 2, dim=-1, largest=False).values
-        if bool((hi[:, k - 1] != hi[:, k]).all() and (lo[:, k - 1] != lo[:, k]).all()):
+        bad = (hi[:, k - 1] == hi[:, k]) | (lo[:, k - 1] == lo[:, k])
+        if not bool(bad.any()):
             return x
         seed += 1000
+        x[bad] = v_tokens(S, Cn, seed)[bad]
+    raise RuntimeError("v_tokens_no_ties: could not remove the ties")
 
 
 def rel_err(a, b, dim=-1):
