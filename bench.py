@@ -133,9 +133,9 @@ def layer_step(lay, q, k, v):
     directly); returns the attention output f32 [1, H, hd]"""
     from kvquant_amd.cache import decode_kv
     if lay.sinks:
-        sink_scores = (torch.bmm(q.unsqueeze(1), lay.k_sink) / math.sqrt(HD)).squeeze(1)        # f16 [H, n_sink]
-        out, sp = decode_kv(lay.k, lay.v, q, k, v, sink_scores)
-        return out + torch.bmm(sp.unsqueeze(1), lay.v_sink).transpose(0, 1).float()
+        # the fp16 sink tokens ride in the same launches (scores: prologue; their share of the output: softmax pass)
+        out, _ = decode_kv(lay.k, lay.v, q, k, v, k_sink=lay.k_sink, v_sink=lay.v_sink)
+        return out
     out, _ = decode_kv(lay.k, lay.v, q, k, v)
     return out
 

@@ -224,6 +224,16 @@ KVQ_API int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores,
  * of the layer that saves the selection workgroup a dependent 256 KB-strided read.
  * klut_score (optional, NULL = klut): the table the score images are built from --
  * the K Q-Norm table at 2 bit (modeling_llama.py:811-815).  vnorm: options of the V append or NULL. */
+/* sinks (optional, NULL = none): the fp16 attention-sink tokens of modeling_llama.py:1464-1466.  The head's table
+ * workgroup also writes the scaled sink scores half(half(q . k_sink) * inv_sqrt_hd) (ML:1950-1962) that
+ * kvq_softmax_finish / kvq_mix_v_softmax take, replacing a torch.matmul and a division per layer. */
+typedef struct kvq_sinks {
+  const uint16_t *k_sink;   /* fp16 [H][128][n_sink], post-RoPE keys */
+  uint16_t *sink_scores;    /* fp16 [H][n_sink] (out) */
+  int n_sink;
+  float inv_sqrt_hd;
+} kvq_sinks;
+
 KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
                         const float *klut_off, const void *k, const float *lo,
                         const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
@@ -232,7 +242,7 @@ KVQ_API int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut,
                         const void *q, int acts_are_half, int thr_k, int H, int hd,
                         int64_t max_len, float *koutliers_t, int32_t *kidx_t,
                         const float *klut_ends, const float *klut_score,
-                        const kvq_vopts *vnorm, void *score_workspace,
+                        const kvq_vopts *vnorm, const kvq_sinks *sinks, void *score_workspace,
                         size_t score_workspace_bytes, void *stream);
 /* kvq_score_k for q_len = 1 with the tables (and the fp32 query copy) already in
  * `workspace` (written by kvq_decode_prologue on the same stream). */
@@ -263,10 +273,15 @@ KVQ_API int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mu
                          const int32_t *outlier_idx_t, void *workspace,
                          size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts,
                          int n_parts, void *stream);
+/* v_sink (optional, with sink_out): fp16 [H][n_sink][128] values of the sink tokens; the workgroup that writes
+ * a head's sink probabilities also writes the sink tokens' share of the attention output,
+ * sink_out[h][c] = float(half(sum_i sink_probs[h][i] * v_sink[h][i][c])) (torch.matmul in fp16, ML:1987-1995), so
+ * that kvq_mix_v with accumulate = 1 completes the layer's output without further launches. */
 KVQ_API int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores,
                        const float *parts, int n_parts, float *probs,
                        uint16_t *sink_probs, int H, int64_t L, int n_sink,
-                       float inv_sqrt_hd, void *stream);
+                       float inv_sqrt_hd, const uint16_t *v_sink, float *sink_out,
+                       void *stream);
 
 /* kvq_softmax_finish + kvq_mix_v (q_len = 1) in ONE streaming pass: the p.V kernel
  * merges the (max, sum) partials itself and turns raw scores into the fp16-rounded
@@ -276,10 +291,11 @@ KVQ_API int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores,
  * the row normaliser is merged in a different order (last-bit differences).  Shapes
  * the streaming kernel does not take (max_len % 4 != 0, H > 128) run the two passes
  * separately through `probs` (float [H][L] scratch; may be NULL otherwise).
+ * v_sink (optional, needs accumulate = 0): as in kvq_softmax_finish, `mul` then also holds the sink tokens' share.
  * workspace: kvq_mix_v_workspace_bytes(bits, 1, H, hd, L). */
 KVQ_API int kvq_mix_v_softmax(int bits, const float *scores, const float *parts, int n_parts,
                       float inv_sqrt_hd, const uint16_t *sink_scores, uint16_t *sink_probs,
-                      int n_sink, float *probs, const int32_t *mat, float *mul,
+                      int n_sink, const uint16_t *v_sink, float *probs, const int32_t *mat, float *mul,
                       const float *lut_rows, int H, int hd, int64_t L, int64_t max_len,
                       const float *outliers, const int32_t *outlier_idx, int n_out,
                       int accumulate, void *workspace, size_t workspace_bytes, void *stream);

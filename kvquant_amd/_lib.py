@@ -20,6 +20,15 @@ class VNorm(ctypes.Structure):
 
 _vn = ctypes.POINTER(VNorm)
 
+
+class Sinks(ctypes.Structure):
+    """struct kvq_sinks of include/kvq.h"""
+    _fields_ = [("k_sink", ctypes.c_void_p), ("sink_scores", ctypes.c_void_p), ("n_sink", ctypes.c_int),
+                ("inv_sqrt_hd", ctypes.c_float)]
+
+
+_sk = ctypes.POINTER(Sinks)
+
 # name -> (restype, argtypes); mirrors include/kvq.h one to one
 SIGNATURES = {
     "kvq_version": (_i, []),
@@ -43,13 +52,13 @@ SIGNATURES = {
     "kvq_softmax_workspace_bytes": (_sz, [_i, _i64]),
     "kvq_softmax_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp, _sz, _vp]),
     "kvq_decode_prologue": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                 _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vn, _vp, _sz, _vp]),
+                                 _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vn, _sk, _vp, _sz, _vp]),
     "kvq_score_k_prepared": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_score_k_softmax_parts": (_i, [_i, _i64, _i]),
     "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                           _sz, _f, _vp, _i, _vp]),
-    "kvq_softmax_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp]),
-    "kvq_mix_v_softmax": (_i, [_i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp, _vp, _i,
+    "kvq_softmax_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp]),
+    "kvq_mix_v_softmax": (_i, [_i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp, _vp, _i,
                                _i, _vp, _sz, _vp]),
     "kvq_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "kvq_append_k_sparse_orig": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),

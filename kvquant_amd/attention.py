@@ -47,6 +47,8 @@ class RotaryDynamic(nn.Module):
 
 
 class KVQuantAttention(nn.Module):
+    fuse_sinks = True     # decode: the fp16 sink tokens' matmuls inside the decode launches (False: torch glue as in the reference)
+
     def __init__(self, hidden_size=4096, num_heads=32, abits=4, include_sparse=True, first_few_fp16=0,
                  maxseqlen=4096, rope_theta=10000.0, sparsity_threshold=0.99, device=None,
                  dtype=torch.float16, bias=False, make_proj=True, use_orig_sparse=False):
@@ -138,9 +140,18 @@ class KVQuantAttention(nn.Module):
 
         # ---- decode over the compressed cache (ML:1948-2006), GPU-resident --------------------------
         sink_scores = None
-        if sinks > 0:
+        fused = self.kcache.include_sparse and self.vcache.include_sparse
+        fuse_sinks = fused and sinks > 0 and self.fuse_sinks and self.kcache_fp16.dtype == torch.float16
+        if sinks > 0 and not fuse_sinks:
             sink_scores = (torch.matmul(query_rope, self.kcache_fp16) / math.sqrt(hd))[0, :, 0, :].contiguous()
-        if self.kcache.include_sparse and self.vcache.include_sparse:
+        if fuse_sinks:
+            # the sink tokens' two fp16 matmuls, division and add ride in the decode launches (decode_kv docstring;
+            # the sum of the two parts is then rounded to fp16 once instead of twice)
+            out, _ = decode_kv(self.kcache, self.vcache, query_rope[0, :, 0, :].contiguous(), key_states.flatten(),
+                               value_states.flatten(), k_sink=self.kcache_fp16[0], v_sink=self.vcache_fp16[0])
+            out = out.transpose(0, 1).half().unsqueeze(0)
+            return out.transpose(1, 2).contiguous().reshape(bsz, q_len, self.hidden_size)
+        if fused:
             out, sink_probs = decode_kv(self.kcache, self.vcache, query_rope[0, :, 0, :].contiguous(),
                                         key_states.flatten(), value_states.flatten(), sink_scores)
             out = out.transpose(0, 1).half()                                   # [H, 1, hd]

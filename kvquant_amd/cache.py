@@ -513,7 +513,7 @@ FUSE_SOFTMAX_INTO_MIX_V = False
 FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", "32768"))
 
 
-def decode_kv(kc, vc, q, k, v, sink_scores=None):
+def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
     """One decode token through a layer's compressed KV path, GPU-resident, 5 launches:
     prologue (K append | V append | K tables) -> q.K^T (+ first softmax pass) -> softmax finish -> p.V -> slab
     reduce.  (FUSE_SOFTMAX_INTO_MIX_V: the p.V kernel normalises the raw scores itself, kvq_mix_v_softmax --
@@ -521,6 +521,10 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     twice: by the workgroup that streams its head's rows and by the one that owns its token's outliers.)
     q: [H, hd] RoPE'd query, k, v: [C] pre-RoPE key / value, all fp16 or all fp32 (no conversion
     launches).  sink_scores: optional f16 [H, n_sink] already scaled scores of the fp16 sink tokens.
+    k_sink (f16 [H, 128, n_sink], post-RoPE) / v_sink (f16 [H, n_sink, 128]) instead: the fp16 sink caches themselves --
+    their scores are computed in the prologue launch and their share of the output in the softmax launch, so that
+    `out` is the complete attention output (the reference's two fp16 matmuls, division and add: ML:1950-1962,
+    1987-1995; five small launches per layer otherwise).
     Returns (out f32 [1, H, hd], sink_probs f16 [H, n_sink] or None).  Sparse (include_sparse) caches only."""
     if not (kc.include_sparse and vc.include_sparse):
         raise ValueError("decode_kv needs include_sparse caches")
@@ -530,11 +534,18 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     lut_off = kc.lookup_table2 if kc.norm else kc.lookup_table
     # the score tables are built from the table the reference dequantises with: the Q-Norm one at 2 bit (ML:811-815)
     table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
+    inv = 1.0 / (kc.head_dim ** 0.5)
+    sinks = None
+    if k_sink is not None:
+        if sink_scores is not None or v_sink is None:
+            raise ValueError("pass either sink_scores or (k_sink, v_sink)")
+        sink_scores = torch.empty((kc.num_heads, k_sink.shape[2]), dtype=torch.float16, device=kc.device)
+        sinks = (k_sink, sink_scores, inv)
     ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
                              kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
                              vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
                              kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t, kc.lut_ends,
-                             None if table is kc.lookup_table else table, vc.vnorm_args())
+                             None if table is kc.lookup_table else table, vc.vnorm_args(), sinks)
     kc.klen += 1
     vc.vlen += 1
     L = kc.klen - kc.first_few_fp16
@@ -543,13 +554,13 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None):
     out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
     if FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO:
         sink_probs = ops.score_k_mix_v(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
-                                       kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), vc.vcache, out,
+                                       kc.outliers, kc.outlier_indices, inv, vc.vcache, out,
                                        vc.mix_table(), vc.outliers, vc.outlier_indices, sink_scores, kc.outliers_t,
-                                       kc.outlier_indices_t)
+                                       kc.outlier_indices_t, v_sink)
         return out, sink_probs
     probs, sink_probs = ops.score_k_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
-                                            kc.outliers, kc.outlier_indices, 1.0 / (kc.head_dim ** 0.5), sink_scores,
-                                            kc.outliers_t, kc.outlier_indices_t)
+                                            kc.outliers, kc.outlier_indices, inv, sink_scores,
+                                            kc.outliers_t, kc.outlier_indices_t, v_sink, out)
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
-              accumulate=False)
+              accumulate=v_sink is not None)
     return out, sink_probs

@@ -36,6 +36,19 @@ __device__ __forceinline__ float prob_fp16(float x, float M, float rZ) {
   return __half2float(__float2half_rn(exp_neg(x - M) * rZ));
 }
 
+// attention output of the fp16 sink tokens for channel c of head h: torch.matmul(probs[:, :n_sink] (fp16),
+// value_states_fp16) (modeling_llama.py:1987-1995) -- fp32 accumulation, ONE rounding to fp16 -- from the sink scores
+// and the row's (max, 1 / normaliser); the probabilities are re-evaluated per lane (n_sink is a handful)
+__device__ __forceinline__ float sink_output(const __half *sink, const __half *v_sink, int n_sink, int h, int c,
+                                             float M, float rZ) {
+  float acc = 0.f;
+  for (int i = 0; i < n_sink; i++) {
+    const float pi = __half2float(__float2half_rn(prob_fp16(__half2float(sink[h * n_sink + i]), M, rZ)));
+    acc = fmaf(pi, __half2float(v_sink[((int64_t)h * n_sink + i) * 128 + c]), acc);
+  }
+  return __half2float(__float2half_rn(acc));
+}
+
 constexpr int kWave = 64;
 constexpr int kHeadDim = 128;  // score / mix kernels (reference BLOCKWIDTH, KCU:43)
 

@@ -449,6 +449,13 @@ struct PrologueArgs {
   unsigned char *tab;      // score workspace: tables, then q as fp32
   float *q32;
   int H;
+  // fp16 attention-sink tokens (optional): scaled scores q . k_sink of head h by the head's table workgroup -- the
+  // reference's torch.matmul(query_states, key_states_fp16) / sqrt(d) (ML:1950-1962): fp32 accumulation, the fp16
+  // result divided in fp16
+  const __half *k_sink;    // [H][128][n_sink], post-RoPE
+  __half *sink_scores;     // [H][n_sink]
+  int n_sink;
+  float sink_inv;
 };
 
 // codes + pack of head h of the new K token (vecquant{b}appendvecK semantics, KCU:1202-1245 ...): the per-head
@@ -494,6 +501,13 @@ __global__ __launch_bounds__(kSelThreads) void decode_prologue_kernel(PrologueAr
     const int h = (int)blockIdx.x - 2;
     quantize_head<BITS>(P.k, h);
     lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.H, h, 0);
+    if (P.k_sink != nullptr && (int)threadIdx.x < P.n_sink) {
+      const int i = threadIdx.x;
+      float acc = 0.f;
+      for (int c = 0; c < kHeadDim; c++)
+        acc = fmaf(ld_act(P.q, h * kHeadDim + c, P.q_is_half), __half2float(P.k_sink[((int64_t)h * kHeadDim + c) * P.n_sink + i]), acc);
+      P.sink_scores[h * P.n_sink + i] = __float2half_rn(scaled(acc, P.sink_inv));
+    }
   }
 }
 
@@ -654,8 +668,11 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
                         float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
                         int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
                         const float *klut_ends, const float *klut_score, const kvq_vopts *vnorm,
-                        void *score_workspace, size_t score_workspace_bytes, void *stream) {
+                        const kvq_sinks *sinks, void *score_workspace, size_t score_workspace_bytes,
+                        void *stream) {
   if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
+  if (sinks != nullptr && sinks->n_sink > 0 && (!sinks->k_sink || !sinks->sink_scores || sinks->n_sink > 1024))
+    return KVQ_EINVAL;
   if (score_workspace_bytes < kvq_score_k_workspace_bytes(bits, 1, H) ||
       reinterpret_cast<uintptr_t>(score_workspace) % 16)
     return KVQ_EWORKSPACE;
@@ -677,6 +694,16 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
   const size_t tabb = bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
   P.q32 = reinterpret_cast<float *>(P.tab + (size_t)H * tabb);
   P.H = H;
+  P.k_sink = nullptr;
+  P.sink_scores = nullptr;
+  P.n_sink = 0;
+  P.sink_inv = 0.f;
+  if (sinks != nullptr && sinks->n_sink > 0) {
+    P.k_sink = reinterpret_cast<const __half *>(sinks->k_sink);
+    P.sink_scores = reinterpret_cast<__half *>(sinks->sink_scores);
+    P.n_sink = sinks->n_sink;
+    P.sink_inv = sinks->inv_sqrt_hd;
+  }
 #if KVQ_TRACE
   {
     unsigned long long *tr = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));

@@ -139,6 +139,8 @@ struct MixArgs {
   const __half *sink;      // [H][n_sink] or null
   __half *sink_probs;
   int n_sink;
+  const __half *v_sink;    // [H][n_sink][128] or null: the sink tokens' output goes to sink_out (= mul, which the reduce accumulates onto)
+  float *sink_out;
   float inv;
 #if KVQ_TRACE
   unsigned long long *trace;   // development: [block][wave][chunk][8]
@@ -520,11 +522,17 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       myM = mz[hc].x;
       myZ = mz[hc].y;
     }
-    if (a.mz == nullptr && blockIdx.x == 0 && a.n_sink > 0)
+    if (a.mz == nullptr && blockIdx.x == 0 && a.n_sink > 0) {
       for (int i = tid; i < a.H * a.n_sink; i += Cfg::NT) {
         const float2 t = mz[i / a.n_sink];
         a.sink_probs[i] = __float2half_rn(prob_fp16(__half2float(a.sink[i]), t.x, t.y));
       }
+      if (a.v_sink != nullptr)
+        for (int i = tid; i < a.H * kHeadDim; i += Cfg::NT) {
+          const float2 t = mz[i / kHeadDim];
+          a.sink_out[i] = sink_output(a.sink, a.v_sink, a.n_sink, i / kHeadDim, i % kHeadDim, t.x, t.y);
+        }
+    }
   }
   // FUSED: raw score -> probability in place, one element per lane; tokens at or past the end of the range get 0
   auto convert_p = [&](int pbuf, int64_t c0) {
@@ -1098,7 +1106,8 @@ __global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restr
 // and the sink probabilities: the part of kvq_softmax_finish that is not per token.  One workgroup per head.
 __global__ __launch_bounds__(256) void softmax_merge_kernel(const float *__restrict__ parts, int n_parts,
                                                             const __half *__restrict__ sink, __half *__restrict__ sink_probs,
-                                                            int n_sink, float *__restrict__ mz) {
+                                                            int n_sink, float *__restrict__ mz,
+                                                            const __half *__restrict__ v_sink, float *__restrict__ sink_out) {
   __shared__ float red[8];
   const int h = blockIdx.x, tid = threadIdx.x;
   const float2 *pr = reinterpret_cast<const float2 *>(parts) + (int64_t)h * n_parts;
@@ -1140,6 +1149,8 @@ __global__ __launch_bounds__(256) void softmax_merge_kernel(const float *__restr
   if (tid == 0) { mz[2 * h] = Mb; mz[2 * h + 1] = Zb; }
   for (int i = tid; i < n_sink; i += 256)
     sink_probs[h * n_sink + i] = __float2half_rn(prob_fp16(__half2float(sink[h * n_sink + i]), Mb, 1.0f / Zb));
+  if (v_sink != nullptr && n_sink > 0)
+    for (int c = tid; c < kHeadDim; c += 256) sink_out[h * kHeadDim + c] = sink_output(sink, v_sink, n_sink, h, c, Mb, 1.0f / Zb);
 }
 
 struct Plan {
@@ -1176,6 +1187,7 @@ struct FusedSoftmax {
   const __half *sink;
   __half *sink_probs;
   int n_sink;
+  const __half *v_sink;
 };
 
 template <int BITS>
@@ -1195,10 +1207,14 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
     a.sink = fs->sink;
     a.sink_probs = fs->sink_probs;
     a.n_sink = fs->n_sink;
+    a.v_sink = fs->v_sink;
+    a.sink_out = mul;
+    if (fs->v_sink != nullptr) accumulate = 1;     // the reduce adds the slabs onto the sink tokens' output
     a.mz = nullptr;
     if (fs->n_parts > kMergeInKernelParts) {
       float *mz = a.sparse_partial + (size_t)pl.n_ranges * pl.groups * a.H * kHeadDim;   // (tail of the workspace)
-      softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz);
+      softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz,
+                                                fs->v_sink, mul);
       int rc0 = check_launch();
       if (rc0) return rc0;
       a.mz = mz;
@@ -1306,6 +1322,8 @@ static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int
   a.sink = nullptr;
   a.sink_probs = nullptr;
   a.n_sink = 0;
+  a.v_sink = nullptr;
+  a.sink_out = nullptr;
   a.inv = 0.f;
 #if KVQ_TRACE
   a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
@@ -1326,20 +1344,22 @@ int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const fl
 }
 
 int kvq_mix_v_softmax(int bits, const float *scores, const float *parts, int n_parts, float inv_sqrt_hd,
-                      const uint16_t *sink_scores, uint16_t *sink_probs, int n_sink, float *probs,
-                      const int32_t *mat, float *mul, const float *lut_rows, int H, int hd, int64_t L,
+                      const uint16_t *sink_scores, uint16_t *sink_probs, int n_sink, const uint16_t *v_sink,
+                      float *probs, const int32_t *mat, float *mul, const float *lut_rows, int H, int hd, int64_t L,
                       int64_t max_len, const float *outliers, const int32_t *outlier_idx, int n_out,
                       int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
   if (!scores || !parts || n_parts <= 0 || n_sink < 0 || H <= 0 || L <= 0) return KVQ_EINVAL;
   if (n_sink > 0 && (!sink_scores || !sink_probs)) return KVQ_EINVAL;
+  if (v_sink != nullptr && (n_sink <= 0 || accumulate)) return KVQ_EINVAL;
   const bool fast = mix_fast_shape(mat, lut_rows, H, hd, L, max_len, bits) && H <= VCfg<4>::MZ_HEADS;
   if (!fast) {
     // shapes the streaming kernel does not take: the two passes separately
     if (!probs) return KVQ_EINVAL;
-    int rc = kvq_softmax_finish(scores, sink_scores, parts, n_parts, probs, sink_probs, H, L, n_sink, inv_sqrt_hd, stream);
+    int rc = kvq_softmax_finish(scores, sink_scores, parts, n_parts, probs, sink_probs, H, L, n_sink, inv_sqrt_hd, v_sink,
+                                mul, stream);
     if (rc) return rc;
-    return mix_v_any(bits, probs, nullptr, mat, mul, lut_rows, 1, H, hd, L, max_len, outliers, outlier_idx, n_out, accumulate,
-                     workspace, workspace_bytes, stream);
+    return mix_v_any(bits, probs, nullptr, mat, mul, lut_rows, 1, H, hd, L, max_len, outliers, outlier_idx, n_out,
+                     v_sink ? 1 : accumulate, workspace, workspace_bytes, stream);
   }
   FusedSoftmax f;
   f.scores = scores;
@@ -1349,6 +1369,7 @@ int kvq_mix_v_softmax(int bits, const float *scores, const float *parts, int n_p
   f.sink = reinterpret_cast<const __half *>(sink_scores);
   f.sink_probs = reinterpret_cast<__half *>(sink_probs);
   f.n_sink = n_sink;
+  f.v_sink = reinterpret_cast<const __half *>(v_sink);
   return mix_v_any(bits, scores, &f, mat, mul, lut_rows, 1, H, hd, L, max_len, outliers, outlier_idx, n_out, accumulate,
                    workspace, workspace_bytes, stream);
 }

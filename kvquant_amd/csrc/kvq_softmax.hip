@@ -95,7 +95,9 @@ __global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restri
                                                             const __half *__restrict__ sink,
                                                             const float *__restrict__ ws, float *__restrict__ probs,
                                                             __half *__restrict__ sink_probs, int64_t L, int n_sink,
-                                                            float inv, int nsplit, int n_parts, int sinks_in_parts) {
+                                                            float inv, int nsplit, int n_parts, int sinks_in_parts,
+                                                            const __half *__restrict__ v_sink = nullptr,
+                                                            float *__restrict__ sink_out = nullptr) {
   __shared__ float red[2 * (NT / 64)];
   const int h = blockIdx.y, sp = blockIdx.x;
   const int64_t per = ((L + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
@@ -156,9 +158,12 @@ __global__ __launch_bounds__(NT) void softmax_final_kernel(const float *__restri
   } else {
     for (int64_t u = t0 + threadIdx.x; u < t1; u += NT) out[u] = f(row[u]);
   }
-  if (sp == 0)
+  if (sp == 0) {
     for (int i = threadIdx.x; i < n_sink; i += NT)
       sink_probs[h * n_sink + i] = __float2half_rn(prob_fp16(__half2float(sink[h * n_sink + i]), M, rZ));
+    if (v_sink != nullptr && n_sink > 0)   // the sink tokens' share of the attention output (kvq_mix_v then accumulates)
+      for (int c = threadIdx.x; c < kHeadDim; c += NT) sink_out[h * kHeadDim + c] = sink_output(sink, v_sink, n_sink, h, c, M, rZ);
+  }
 }
 
 static int pick_split(int H, int64_t L) {
@@ -203,16 +208,17 @@ int kvq_softmax_scale(const float *scores, const uint16_t *sink_scores, float *p
 
 int kvq_softmax_finish(const float *scores, const uint16_t *sink_scores, const float *parts, int n_parts,
                        float *probs, uint16_t *sink_probs, int H, int64_t L, int n_sink, float inv_sqrt_hd,
-                       void *stream) {
+                       const uint16_t *v_sink, float *sink_out, void *stream) {
   if (!scores || !probs || !parts || n_parts <= 0 || H <= 0 || L <= 0 || n_sink < 0) return KVQ_EINVAL;
   if (n_sink > 0 && (!sink_scores || !sink_probs)) return KVQ_EINVAL;
+  if (v_sink != nullptr && (n_sink <= 0 || !sink_out)) return KVQ_EINVAL;
   // 1024-lane workgroups: the (max, sum) merge of the row's partials (one per 256-token tile of the score
   // kernel) is paid once per 1024 lanes and the streaming part runs at 8 waves per SIMD
   const int nsplit = pick_split(H, L);
   dim3 grid(nsplit, H), block(1024);
   softmax_final_kernel<1024><<<grid, block, 0, (hipStream_t)stream>>>(
       scores, reinterpret_cast<const __half *>(sink_scores), parts, probs, reinterpret_cast<__half *>(sink_probs), L,
-      n_sink, inv_sqrt_hd, nsplit, n_parts, 0);
+      n_sink, inv_sqrt_hd, nsplit, n_parts, 0, reinterpret_cast<const __half *>(v_sink), sink_out);
   return check_launch();
 }
 

@@ -358,11 +358,20 @@ def _act(t, name):
 
 def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vmat, vlut_rows, vlut_sorted, v,
                     voutl, vidx, vcol, q, thr_k, koutl_t=None, kidx_t=None, klut_ends=None, klut_score=None,
-                    vnorm=None):
+                    vnorm=None, sinks=None):
     """K fused append + V fused append + K codebook images for score_k_prepared in ONE launch.
     q [H,128] (RoPE'd), k, v [C]: all fp32 or all fp16.  klut_score: table the score images are built from
-    (default klut).  Returns the score workspace tensor."""
+    (default klut).  sinks = (k_sink f16 [H, 128, n_sink], sink_scores f16 [H, n_sink] (out), inv_sqrt_hd): the head
+    workgroups also write the scaled scores of the fp16 sink tokens.  Returns the score workspace tensor."""
     H, hd, max_len = _cache_dims(kmat, bits)
+    sk = None
+    if sinks is not None:
+        k_sink, sink_scores, inv = sinks
+        n_sink = sink_scores.shape[1]
+        if tuple(k_sink.shape) != (H, 128, n_sink) or sink_scores.shape[0] != H:
+            raise ValueError("sinks: k_sink [H, 128, n_sink] and sink_scores [H, n_sink] expected")
+        sk = _lib.Sinks(_chk(k_sink, torch.float16, "k_sink"), _chk(sink_scores, torch.float16, "sink_scores"), n_sink,
+                        float(inv))
     kp, kh = _act(k, "k")
     vp, vh = _act(v, "v")
     qp, qh = _act(q, "q")
@@ -378,7 +387,7 @@ def decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutl, kidx, kcol, vm
             _i(vidx, "outlier_indices"), int(vcol), qp, kh, int(thr_k), H, hd, max_len,
             *_mirror(koutl_t, kidx_t, thr_k, max_len), None if klut_ends is None else _f(klut_ends, "lut_ends"),
             None if klut_score is None else _f(klut_score, "lut_score"), _vnorm(vnorm),
-            ws.data_ptr(), ws.numel(), _stream()), "kvq_decode_prologue")
+            None if sk is None else ctypes.byref(sk), ws.data_ptr(), ws.numel(), _stream()), "kvq_decode_prologue")
     return ws
 
 
@@ -411,38 +420,45 @@ def score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outl
     return parts
 
 
-def softmax_finish(scores, parts, n_parts, inv_sqrt_hd, sink_scores=None):
-    """second softmax pass on partials written by score_k_prepared_softmax; scores f32 [H, L]."""
+def softmax_finish(scores, parts, n_parts, inv_sqrt_hd, sink_scores=None, v_sink=None, sink_out=None):
+    """second softmax pass on partials written by score_k_prepared_softmax; scores f32 [H, L].
+    v_sink (f16 [H, n_sink, 128]) + sink_out (f32 [1, H, 128]): the sink tokens' share of the attention output is
+    written to sink_out by the same launch (mix_v then accumulates onto it)."""
     H, L = scores.shape
     n_sink = 0 if sink_scores is None else sink_scores.shape[1]
     probs = torch.empty_like(scores)
     sink_probs = None if n_sink == 0 else torch.empty_like(sink_scores)
+    if v_sink is not None and (n_sink == 0 or sink_out is None or tuple(v_sink.shape) != (H, n_sink, 128)):
+        raise ValueError("v_sink needs sink_scores, sink_out and the shape [H, n_sink, 128]")
     with _Dev(scores):
         _lib.check(_L().kvq_softmax_finish(
             _f(scores, "scores"), None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"),
             parts.data_ptr(), n_parts, _f(probs, "probs"), None if n_sink == 0 else sink_probs.data_ptr(), H, L,
-            n_sink, float(inv_sqrt_hd), _stream()), "kvq_softmax_finish")
+            n_sink, float(inv_sqrt_hd), None if v_sink is None else _chk(v_sink, torch.float16, "v_sink"),
+            None if v_sink is None else _f(sink_out, "sink_out"), _stream()), "kvq_softmax_finish")
     return probs, sink_probs
 
 
 def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices, inv_sqrt_hd,
-                    sink_scores=None, outliers_t=None, outlier_indices_t=None):
+                    sink_scores=None, outliers_t=None, outlier_indices_t=None, v_sink=None, sink_out=None):
     """q.K^T (tables already in `ws`) + softmax: `mul` [1, H, L] receives the raw scores; returns
     (probs f32 [H, L] holding fp16 values, sink_probs f16 [H, n_sink] or None).  Sparse caches take the
     score kernel with the first softmax pass fused in (2 launches), others score_k_prepared +
     softmax_scale (3 launches)."""
     n_parts = _L().kvq_score_k_softmax_parts(bits, int(L), 1 if outliers is not None else 0)
     if n_parts == 0:
+        if v_sink is not None:
+            raise ValueError("v_sink needs the fused softmax partials (sparse cache)")
         score_k_prepared(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices)
         return softmax_scale(mul[0], inv_sqrt_hd, sink_scores)
     parts = score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices,
                                      inv_sqrt_hd, n_parts, outliers_t, outlier_indices_t)
-    return softmax_finish(mul[0], parts, n_parts, inv_sqrt_hd, sink_scores)
+    return softmax_finish(mul[0], parts, n_parts, inv_sqrt_hd, sink_scores, v_sink, sink_out)
 
 
 def score_k_mix_v(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices, inv_sqrt_hd,
                   vmat, out, vlut_rows, voutliers, voutlier_indices, sink_scores=None, koutliers_t=None,
-                  koutlier_indices_t=None):
+                  koutlier_indices_t=None, v_sink=None):
     """q.K^T (tables already in `ws`) -> softmax -> p.V of one decode token in two streaming launches + the slab
     reduce: the score kernel writes raw scores and per-tile softmax partials, the p.V kernel normalises on the way
     (kvq_mix_v_softmax).  scores [1, H, L] scratch, out f32 [1, H, hd].  Returns sink_probs (f16 [H, n_sink]) or None."""
@@ -450,19 +466,21 @@ def score_k_mix_v(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers,
     if n_parts == 0 or voutliers is None:
         probs, sink_probs = score_k_softmax(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers,
                                             koutlier_indices, inv_sqrt_hd, sink_scores, koutliers_t,
-                                            koutlier_indices_t)
-        mix_v(bits, probs.unsqueeze(0), vmat, out, vlut_rows, L, voutliers, voutlier_indices, accumulate=False)
+                                            koutlier_indices_t, v_sink, out)
+        mix_v(bits, probs.unsqueeze(0), vmat, out, vlut_rows, L, voutliers, voutlier_indices,
+              accumulate=v_sink is not None)
         return sink_probs
     parts = score_k_prepared_softmax(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices,
                                      inv_sqrt_hd, n_parts, koutliers_t, koutlier_indices_t)
     return mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, vmat, out, vlut_rows, L, voutliers,
-                         voutlier_indices, sink_scores)
+                         voutlier_indices, sink_scores, v_sink)
 
 
 def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows, L, outliers, outlier_indices,
-                  sink_scores=None):
+                  sink_scores=None, v_sink=None):
     """kvq_mix_v_softmax: raw scores [1, H, L] + the score kernel's softmax partials -> mul f32 [1, H, hd]
-    (overwritten); returns sink_probs (f16 [H, n_sink]) or None."""
+    (overwritten; with v_sink f16 [H, n_sink, 128] it includes the sink tokens' share); returns sink_probs
+    (f16 [H, n_sink]) or None."""
     H, hd, max_len = _cache_dims(mat, bits)
     n_sink = 0 if sink_scores is None else sink_scores.shape[1]
     sink_probs = None if n_sink == 0 else torch.empty_like(sink_scores)
@@ -475,7 +493,9 @@ def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows,
         _lib.check(_L().kvq_mix_v_softmax(
             bits, _f(scores, "scores"), parts.data_ptr(), n_parts, float(inv_sqrt_hd),
             None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"),
-            None if n_sink == 0 else sink_probs.data_ptr(), n_sink, None if probs is None else probs.data_ptr(),
+            None if n_sink == 0 else sink_probs.data_ptr(), n_sink,
+            None if v_sink is None else _chk(v_sink, torch.float16, "v_sink"),
+            None if probs is None else probs.data_ptr(),
             _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), H, hd, int(L), max_len,
             _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outliers.shape[1], 0, wsv.data_ptr(),
             wsv.numel(), _stream()), "kvq_mix_v_softmax")

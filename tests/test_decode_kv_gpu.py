@@ -158,3 +158,47 @@ def test_decode_kv_other_model_widths(bits, heads, prefill, max_len):
         pytest.skip("no GPU")
     err = decode_check.run(torch.device("cuda:0"), bits=bits, prefill=prefill, steps=3, max_len=max_len, heads=heads)
     assert err < 2e-3
+
+
+@pytest.mark.parametrize("bits,prefill,max_len", [(4, 200, 256), (3, 1000, 1024), (4, 40000, 40064)])
+def test_fused_sinks_match_torch_glue(bits, prefill, max_len):
+    """decode_kv with the fp16 sink caches handed in (scores in the prologue launch, output share in the softmax launch)
+    against the reference's glue around it (torch.matmul / division before, torch.matmul + add after, ML:1950-1962,
+    1987-1995) on identical caches: sink probabilities to an fp16 ulp, outputs to the decode tolerance.  The short
+    caches take the p.V kernel that normalises the scores itself, the long one the softmax-finish launch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import math
+    from kvquant_amd.cache import QuantK, QuantV, decode_kv
+    dev = torch.device("cuda:0")
+    H, HD, C = decode_check.H, decode_check.HD, decode_check.C
+    n_sink = 5
+    quant, scale, shift = decode_check.quantizer(bits, seed=9 + bits)
+    g = torch.Generator().manual_seed(prefill + 17 * bits)
+    kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+              sparsity_threshold=0.99, first_few_fp16=n_sink, device=dev)
+    pairs = []
+    k = (torch.randn(C, prefill, generator=g) * scale[:, None] * 1.3 + shift[:, None]).reshape(H, HD, prefill).to(dev)
+    v = (torch.randn(C, prefill, generator=g) * 1.7).reshape(H, HD, prefill).to(dev)
+    for _ in range(2):
+        kc, vc = QuantK(rope_theta=10000.0, **kw), QuantV(**kw)
+        kc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        vc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        kc.klen = vc.vlen = n_sink
+        kc.parallel_pack(k)
+        vc.parallel_pack(v)
+        pairs.append((kc, vc))
+    k_sink = (torch.randn(H, HD, n_sink, generator=g) * 0.6).half().to(dev)
+    v_sink = torch.randn(H, n_sink, HD, generator=g).half().to(dev)
+    for step in range(2):
+        q = torch.randn(H, HD, generator=g).half().to(dev)
+        kn = (torch.randn(C, generator=g) * scale * 1.3 + shift).half().to(dev)
+        vn = (torch.randn(C, generator=g) * 1.7).half().to(dev)
+        sink_scores = (torch.bmm(q.unsqueeze(1), k_sink) / math.sqrt(HD)).squeeze(1)
+        out_ref, sp_ref = decode_kv(pairs[0][0], pairs[0][1], q, kn, vn, sink_scores)
+        out_ref = out_ref + torch.bmm(sp_ref.unsqueeze(1), v_sink).transpose(0, 1).float()
+        out, sp = decode_kv(pairs[1][0], pairs[1][1], q, kn, vn, k_sink=k_sink, v_sink=v_sink)
+        torch.cuda.synchronize()
+        assert (sp.float() - sp_ref.float()).abs().max().item() <= 2e-3 * sp_ref.float().abs().max().item() + 1e-7
+        scale_o = out_ref.abs().max().item() + 1e-6
+        assert (out - out_ref).abs().max().item() <= 2e-3 * scale_o, step
