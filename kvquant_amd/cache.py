@@ -516,9 +516,10 @@ FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", "32768"))
 def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
     """One decode token through a layer's compressed KV path, GPU-resident, 5 launches:
     prologue (K append | V append | K tables) -> q.K^T (+ first softmax pass) -> softmax finish -> p.V -> slab
-    reduce.  (FUSE_SOFTMAX_INTO_MIX_V: the p.V kernel normalises the raw scores itself, kvq_mix_v_softmax --
-    measured SLOWER at 128K, 93 vs 88 us for the pair of launches, because every probability is then evaluated
-    twice: by the workgroup that streams its head's rows and by the one that owns its token's outliers.)
+    reduce; 4 launches up to FUSE_SOFTMAX_UP_TO cached tokens, where the p.V kernel normalises the raw scores
+    itself (kvq_mix_v_softmax: 4K contexts 3.04 -> 2.65 ms per 32-layer step).  For long caches that fusion is
+    SLOWER (FUSE_SOFTMAX_INTO_MIX_V: 93 vs 88 us at 128K for the pair of launches, because every probability is then
+    evaluated twice: by the workgroup that streams its head's rows and by the one that owns its token's outliers).
     q: [H, hd] RoPE'd query, k, v: [C] pre-RoPE key / value, all fp16 or all fp32 (no conversion
     launches).  sink_scores: optional f16 [H, n_sink] already scaled scores of the fp16 sink tokens.
     k_sink (f16 [H, 128, n_sink], post-RoPE) / v_sink (f16 [H, n_sink, 128]) instead: the fp16 sink caches themselves --
