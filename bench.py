@@ -20,7 +20,9 @@ set_devices (modeling_llama.py:2428-2453) and N decode streams are kept in fligh
 the 8 KB activation moves between neighbouring ranks point-to-point over RCCL (no collective on the data path).
 Per-GPU work is fixed as N grows (32/N layers x N streams x ctx): weak scaling, value = all streams' tokens per
 second.  --streams 1 is the reference's capacity mode (one long-context stream); --replicas keeps the old
-"N independent 32-layer copies" mode.
+"N independent 32-layer copies" mode.  --shard tokens: ONE stream whose context is split along the token axis (every
+rank streams ctx / N tokens of every layer, one all-gather of [H, hd + 2] floats per layer merges the shards exactly):
+the placement that speeds a single long stream up; strong scaling.
 """
 import argparse
 import json
@@ -52,6 +54,9 @@ def parse():
                     help="first_few_fp16 attention-sink tokens kept in fp16 (BASELINE config 3: --bits 3 --sinks 5)")
     ap.add_argument("--streams", type=int, default=0, help="decode streams in flight (default: one per rank)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent full copies instead of layer sharding")
+    ap.add_argument("--shard", choices=("layers", "tokens"), default="layers",
+                    help="N > 1: layers = the reference's placement, N streams pipelined through it (default); tokens = ONE "
+                         "stream whose context is split along the token axis (strong scaling, one all-gather per layer)")
     ap.add_argument("--sweep", action="store_true", help="every BASELINE configuration, one JSON line each (1 GPU)")
     ap.add_argument("--retrieval", action="store_true", help="plant a retrievable token and check it (config 5 proxy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -323,6 +328,80 @@ def check_retrieval(lay, q, dev):
             "ok": top1 >= (3 * H) // 4 and err is not None and err < 5e-3}
 
 
+def run_token_sharded(args, rank, world, dev, dist):
+    """--shard tokens: ONE decode stream, every rank holds ctx / N cached tokens of every layer
+    (kvquant_amd.cache.shard_attention), the newest tokens live on the last rank; per layer one all-gather of
+    [H, hd + 2] floats merges the shards exactly (sharding.token_sharded_step).  Strong scaling: the total work is
+    fixed as N grows.  Returns the result dict on rank 0."""
+    from kvquant_amd import sharding
+    from kvquant_amd.cache import shard_attention
+    total = args.steps + args.warmup
+    per = (args.ctx + world - 1) // world
+    lo = rank * per
+    n_here = max(0, min(args.ctx, lo + per) - lo)
+    last = rank == world - 1
+    max_len = (n_here + (total if last else 0) + 8 + 63) // 64 * 64
+    gen = torch.Generator(device=dev).manual_seed(1234)          # the same queries / new tokens on every rank
+    t_setup = time.time()
+    layers = []
+    for li in range(args.layers):
+        lay = Layer(args.bits, max_len, gen, dev, 0)
+        lay.fill(n_here, torch.Generator(device=dev).manual_seed(77 + 1000 * rank + li), dev)
+        k, v = synth_tokens(total, lay.scale, lay.shift, gen, dev)
+        q = torch.randn(total, H, HD, generator=gen, device=dev).half()
+        layers.append((lay, q, k, v))
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def step(st):
+        out = None
+        for lay, q, k, v in layers:
+            qq = q[st] if out is None else q[st] + out.view(H, HD).half() * 1e-3      # (a true dependency on the merge)
+            fn = (lambda: shard_attention(lay.k, lay.v, qq, k[st], v[st], pos_base=lo)) if last else \
+                (lambda: shard_attention(lay.k, lay.v, qq, pos_base=lo))
+            out = sharding.token_sharded_step(fn)
+        return out
+
+    for st in range(args.warmup):
+        step(st)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for st in range(args.warmup, total):
+        step(st)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    kb, per_tok = algorithmic_bytes(args.bits, n_here, "score_k")
+    vb, _ = algorithmic_bytes(args.bits, n_here, "mix_v")
+    return {
+        "metric": "decode tokens/s, KV-cache hot path (%d layers), LLaMA-2-7B head shape, nuq%d 1%%-sparse @%dK ctx, ONE "
+                  "stream, context split along the token axis over %d GPU(s)" % (args.layers, args.bits, args.ctx // 1024, world),
+        "value": args.steps / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1000.0 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LLaMA-2-7B KV path: H=32 hd=128 layers=%d nuq%d + 1%% outliers, ctx=%d cached tokens, 1 stream"
+                               % (args.layers, args.bits, args.ctx),
+                   "ctx": args.ctx, "bits": args.bits, "layers": args.layers, "streams": 1,
+                   "parallelism": "token-sharded over %d GPU(s): %d tokens per GPU, one all-gather of [H, hd + 2] f32 per layer"
+                                  % (world, per)},
+        "roofline": {"bound": "hbm", "kernel": "score_k + mix_v per GPU", "achieved": args.layers * (kb + vb) / (elapsed / args.steps) / 1e9,
+                     "peak": 8000.0, "unit": "GB/s", "frac": args.layers * (kb + vb) / (elapsed / args.steps) / 1e9 / 8000.0,
+                     "traffic": None, "bytes_per_token": per_tok},
+        "cpu_baseline": None, "setup_s": t_setup,
+    }
+
+
 def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
     """build the caches of one configuration, time args.steps decode steps, return the result dict (rank 0) or None"""
     from kvquant_amd import sharding
@@ -499,7 +578,10 @@ def main():
             a.retrieval = ctx >= 1048576
             r = run_config(a, rank, world, dev, dist, label=label, with_baselines=False)
             print(json.dumps(r), flush=True)
-    res = run_config(args, rank, world, dev, dist)
+    if args.shard == "tokens":
+        res = run_token_sharded(args, rank, world, dev, dist)
+    else:
+        res = run_config(args, rank, world, dev, dist)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

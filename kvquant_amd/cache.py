@@ -565,3 +565,67 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
               accumulate=v_sink is not None)
     return out, sink_probs
+
+
+def shard_attention(kc, vc, q, k=None, v=None, pos_base=0):
+    """Attention of one decode token over ONE SHARD of a context that is split along the token axis (SURVEY 8e asks
+    for layer / head placement; this is the third cut, the one that speeds up a single long stream: every GPU holds
+    L / N cached tokens of every layer and streams only those).  kc / vc hold the shard's tokens, whose positions
+    start at `pos_base`; k, v (the new token) are appended to THIS shard when given -- the owner of the newest tokens
+    -- and the other shards only score.  Returns (out f32 [1, H, hd] normalised over the shard, M f32 [H], Z f32 [H]):
+    the shard's softmax maximum and normaliser of the scaled fp16 scores, from the score kernel's partials, so that
+    `combine_shards` can merge the shards exactly (flash-decoding across devices; the probabilities are rounded to
+    fp16 per shard instead of over the whole row, a last-bit effect).  Sparse caches with the outlier mirror."""
+    if not (kc.include_sparse and vc.include_sparse):
+        raise ValueError("shard_attention needs include_sparse caches")
+    bits, H = kc.bits, kc.num_heads
+    inv = 1.0 / (kc.head_dim ** 0.5)
+    table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
+    pos_offset = kc.first_few_fp16 + int(pos_base)
+    if k is not None:
+        kpos = kc.klen - kc.first_few_fp16
+        vpos = vc.vlen - vc.first_few_fp16
+        lut_off = kc.lookup_table2 if kc.norm else kc.lookup_table
+        ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
+                                 kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
+                                 vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
+                                 kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t, kc.lut_ends,
+                                 None if table is kc.lookup_table else table, vc.vnorm_args())
+        kc.klen += 1
+        vc.vlen += 1
+    else:
+        # tables of q into the score workspace (the score entry point builds them before its kernel)
+        dummy = torch.zeros((1, H, 1), dtype=torch.float32, device=kc.device)
+        ops.score_k(bits, q.float().unsqueeze(0).contiguous(), kc.kcache, dummy, table, 1, kc.rope_theta, 0,
+                    accumulate=False)
+        ws = ops._workspace(kc.device, ops._L().kvq_score_k_workspace_bytes(bits, 1, H), slot="score")
+    L = kc.klen - kc.first_few_fp16
+    scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
+    out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
+    n_parts = ops._L().kvq_score_k_softmax_parts(bits, L, 1)
+    if n_parts > 0:
+        parts = ops.score_k_prepared_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, pos_offset, ws,
+                                             kc.outliers, kc.outlier_indices, inv, n_parts, kc.outliers_t,
+                                             kc.outlier_indices_t)
+        pm = parts[:H * n_parts * 8].view(torch.float32).view(H, n_parts, 2)
+        M = pm[..., 0].max(dim=-1).values
+        Z = (pm[..., 1] * torch.exp(pm[..., 0] - M[:, None])).sum(dim=-1)
+        probs, _ = ops.softmax_finish(scores[0], parts, n_parts, inv)
+    else:
+        ops.score_k_prepared(bits, kc.kcache, scores, table, L, kc.rope_theta, pos_offset, ws, kc.outliers,
+                             kc.outlier_indices)
+        sc = (scores[0].half() * inv).float()       # half(half(s) * inv), as the kernels scale
+        M = sc.max(dim=-1).values
+        Z = torch.exp(sc - M[:, None]).sum(dim=-1)
+        probs, _ = ops.softmax_scale(scores[0], inv)
+    ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
+              accumulate=False)
+    return out, M, Z
+
+
+def combine_shards(outs, Ms, Zs):
+    """exact merge of per-shard attention: out = sum_r w_r out_r / sum_r w_r with w_r = Z_r exp(M_r - max_r M_r).
+    outs [R, 1, H, hd], Ms / Zs [R, H] (stacked over the shards, any device)."""
+    Mg = Ms.max(dim=0).values
+    w = Zs * torch.exp(Ms - Mg[None, :])                   # [R, H]
+    return (outs * w[:, None, :, None]).sum(dim=0) / w.sum(dim=0)[None, :, None]

@@ -160,3 +160,22 @@ class StreamPipeline:
         for q, _ in sends:
             q.wait()
         return finals if r == 0 else []
+
+
+def token_sharded_step(shard_fn, group=None):
+    """One decode step of ONE stream whose context is split along the token axis over the ranks of `group`
+    (`kvquant_amd.cache.shard_attention` on each rank's shard): every rank streams only its L / N cached tokens, then
+    ONE all-gather of [H, hd + 2] floats per layer (17 KB at the 7B shape; flat over the direct xGMI links) carries the
+    shards' outputs and softmax statistics, and every rank forms the exact merged output (`combine_shards`).
+    shard_fn() -> (out [1, H, hd], M [H], Z [H]) for this rank's shard.  Returns the merged [1, H, hd] on every rank."""
+    from .cache import combine_shards
+    out, M, Z = shard_fn()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return out
+    packed = torch.cat((out[0], M[:, None], Z[:, None]), dim=-1).contiguous()          # [H, hd + 2]
+    bufs = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(bufs, packed, group=group)
+    allp = torch.stack(bufs)                                                            # [R, H, hd + 2]
+    hd = out.shape[-1]
+    return combine_shards(allp[:, None, :, :hd], allp[:, :, hd], allp[:, :, hd + 1])

@@ -202,3 +202,46 @@ def test_fused_sinks_match_torch_glue(bits, prefill, max_len):
         assert (sp.float() - sp_ref.float()).abs().max().item() <= 2e-3 * sp_ref.float().abs().max().item() + 1e-7
         scale_o = out_ref.abs().max().item() + 1e-6
         assert (out - out_ref).abs().max().item() <= 2e-3 * scale_o, step
+
+
+@pytest.mark.parametrize("bits,S,split,sinks", [(4, 700, 300, 0), (4, 9000, 4096, 0), (3, 1200, 640, 5), (4, 40, 10, 0)])
+def test_token_sharded_attention_matches_unsharded(bits, S, split, sinks):
+    """cache.shard_attention over two shards of a context split along the token axis (positions of the second shard
+    start at `split`; the new token is appended to it) + combine_shards against decode_kv on the unsharded cache:
+    the same attention output to the decode tolerance (probabilities are rounded to fp16 per shard)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd.cache import QuantK, QuantV, decode_kv, shard_attention, combine_shards
+    dev = torch.device("cuda:0")
+    H, HD, C = decode_check.H, decode_check.HD, decode_check.C
+    quant, scale, shift = decode_check.quantizer(bits, seed=21 + bits)
+    g = torch.Generator().manual_seed(S + bits)
+    k = (torch.randn(C, S, generator=g) * scale[:, None] * 1.3 + shift[:, None]).reshape(H, HD, S).to(dev)
+    v = (torch.randn(C, S, generator=g) * 1.7).reshape(H, HD, S).to(dev)
+
+    def make(ks, vs, max_len):
+        kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+                  sparsity_threshold=0.99, first_few_fp16=sinks, device=dev)
+        kc, vc = QuantK(rope_theta=10000.0, **kw), QuantV(**kw)
+        kc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        vc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        kc.klen = vc.vlen = sinks
+        if ks.shape[-1]:
+            kc.parallel_pack(ks.contiguous())
+            vc.parallel_pack(vs.contiguous())
+        return kc, vc
+
+    full = make(k, v, (S + 64 + 63) // 64 * 64)
+    s0 = make(k[:, :, :split], v[:, :, :split], (split + 63) // 64 * 64)
+    s1 = make(k[:, :, split:], v[:, :, split:], (S - split + 64 + 63) // 64 * 64)
+    for step in range(2):
+        q = torch.randn(H, HD, generator=g).half().to(dev)
+        kn = (torch.randn(C, generator=g) * scale * 1.3 + shift).half().to(dev)
+        vn = (torch.randn(C, generator=g) * 1.7).half().to(dev)
+        ref, _ = decode_kv(full[0], full[1], q, kn, vn)
+        o0, m0, z0 = shard_attention(s0[0], s0[1], q, pos_base=0)
+        o1, m1, z1 = shard_attention(s1[0], s1[1], q, kn, vn, pos_base=split)
+        out = combine_shards(torch.stack((o0, o1)), torch.stack((m0, m1)), torch.stack((z0, z1)))
+        torch.cuda.synchronize()
+        scale_o = ref.abs().max().item() + 1e-6
+        assert (out - ref).abs().max().item() <= 2e-3 * scale_o, step

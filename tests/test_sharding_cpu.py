@@ -118,3 +118,49 @@ def test_stream_pipeline_over_gloo(world, n_layers, streams):
         for i in range(n_layers):
             ref = ref * 1.25 + float(i) + 0.01 * (st + 1) + 100.0 * s
         assert torch.allclose(outs[k], ref, rtol=0, atol=0), (st, s)
+
+
+def _token_shard_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kvquant_amd import sharding
+        H, hd, L = 4, 8, 96
+        g = torch.Generator().manual_seed(5)
+        s = torch.randn(H, L, generator=g) * 3                 # scaled scores of the whole row
+        v = torch.randn(H, L, hd, generator=g)
+        per = L // world
+        sl = slice(rank * per, (rank + 1) * per if rank < world - 1 else L)
+
+        def shard_fn():                                        # plain-torch stand-in for cache.shard_attention
+            ss, vv = s[:, sl], v[:, sl]
+            M = ss.max(dim=-1).values
+            e = torch.exp(ss - M[:, None])
+            Z = e.sum(dim=-1)
+            return torch.einsum("hl,hld->hd", e / Z[:, None], vv)[None], M, Z
+
+        out = sharding.token_sharded_step(shard_fn)
+        ref = torch.einsum("hl,hld->hd", torch.softmax(s, dim=-1), v)[None]
+        q.put((rank, float((out - ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_token_sharded_step_merges_exactly(world):
+    """the all-gather + combine of sharding.token_sharded_step over gloo: the merged attention of a row split over the
+    ranks equals the unsharded softmax . V"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + world
+    procs = [ctx.Process(target=_token_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(err < 1e-5 for _, err in res), res
