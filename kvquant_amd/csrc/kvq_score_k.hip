@@ -52,6 +52,15 @@
 #ifndef KVQ_K_SPARSE_AFTER
 #define KVQ_K_SPARSE_AFTER 0   // mirror variant: the outlier entries in batches after the head loop instead of one per head iteration
 #endif
+#ifndef KVQ_K_JIT
+#define KVQ_K_JIT 1            // mirror variant: packed-word registers are re-loaded for head h+2 as soon as head h has consumed them
+#endif
+#ifndef KVQ_K_NACC
+#define KVQ_K_NACC (KVQ_K_JIT ? 2 : 4)   // independent packed accumulators of the dense loop (4 bit)
+#endif
+#ifndef KVQ_K_LKB
+#define KVQ_K_LKB (KVQ_K_JIT ? 2 : 4)    // rotation pairs per look-up batch (4 bit): 2 * LKB ds_read_b64 in flight per wave
+#endif
 #ifndef KVQ_TRACE
 #define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the head loop (tools/dbg/trace_k.py)
 #endif
@@ -150,6 +159,15 @@ void score_k_kernel(ScoreKArgs a) {
   //  then and takes over a table buffer: three buffers fit the same 80 KB)
   constexpr bool LATE_Q = TRANSPOSED && KVQ_K_SPARSE_AFTER && KVQ_K_PF3;
   constexpr int PF = (SPARSE && !LATE_Q) ? 2 : 3;
+  // JIT (mirror variant): two register sets, but a set is re-loaded for head h+2 while head h is still being decoded
+  // -- each pair of word registers right after the batch that consumed it -- and the outlier entry of head h+2 right
+  // after the one of head h has been used.  The loads of a head are then in flight for one to two head iterations
+  // (what a third register set would buy) and leave the wave spread over the look-ups instead of in one burst behind
+  // the barrier.  Memory operations return in order, so at the top of head h+1 `s_waitcnt vmcnt(JIT_OPS)` -- all but
+  // the JIT_OPS operations issued during head h -- covers exactly what head h+1 needs: its table (issued at the top
+  // of head h), its words and its outlier entry (issued during head h-1).
+  constexpr bool JIT = KVQ_K_JIT && TRANSPOSED && !KVQ_K_SPARSE_AFTER && PF == 2;
+  constexpr int JIT_OPS = 2 * BITS + 2;
   // VMEM operations of one look-ahead step that EVERY wave issues (waves with an extra table piece wait
   // for one more than they need to)
   constexpr int STEP_OPS = 2 * BITS + TAB_DMA / NWAVES;
@@ -282,9 +300,24 @@ void score_k_kernel(ScoreKArgs a) {
     load_words<BITS>(whi_all[set], hb + hi_words, a.max_len, woff);
     if (acc_dense) load_old(oldv[set], hh);
   };
-  static_for<0, PF - 1>([&](auto U) {
-    if (decltype(U)::value < nh) fetch_head(decltype(U)::value, U);
-  });
+  if constexpr (JIT) {
+    // table 0, then the words and the outlier entry of head 0 (set 0) and -- the JIT_OPS operations that may still be
+    // in flight at the top of head 0 -- those of head 1 (set 1)
+    issue_table(0, 0);
+    load_words<BITS>(wlo_all[0], mat_h0, a.max_len, woff);
+    load_words<BITS>(whi_all[0], mat_h0 + hi_words, a.max_len, woff);
+    sparse_fetch_t(0, spv_all[0], spc_all[0]);
+    {
+      const uint32_t *h1 = mat_h0 + (nh > 1 ? head_words : 0);     // (a single head: the same rows again, never used)
+      load_words<BITS>(wlo_all[1], h1, a.max_len, woff);
+      load_words<BITS>(whi_all[1], h1 + hi_words, a.max_len, woff);
+      sparse_fetch_t(per_t > 1 ? 1 : 0, spv_all[1], spc_all[1]);
+    }
+  } else {
+    static_for<0, PF - 1>([&](auto U) {
+      if (decltype(U)::value < nh) fetch_head(decltype(U)::value, U);
+    });
+  }
 
   __syncthreads();   // sc / ql visible
 
@@ -353,7 +386,9 @@ void score_k_kernel(ScoreKArgs a) {
 
   // first look-ahead set: after the barrier above (its latency hides behind the trig below), checked like
   // every other asm load by tools/check_isa.py
-  if constexpr (TRANSPOSED) {
+  if constexpr (JIT) {
+    // (both sets were requested above)
+  } else if constexpr (TRANSPOSED) {
 #if !KVQ_K_SPARSE_AFTER
     if (nsteps > 0) sparse_fetch_t(0, spv_all[0], spc_all[0]);
 #endif
@@ -416,7 +451,9 @@ void score_k_kernel(ScoreKArgs a) {
     stamp(0);
 #endif
     // this head's table and words were requested PF-1 heads ago; younger requests may stay in flight
-    if (PF > 2 && hh + 1 < nh) {
+    if constexpr (JIT) {
+      vm_wait<JIT_OPS>();   // (what head hh-1 issued for head hh+1 may stay in flight)
+    } else if (PF > 2 && hh + 1 < nh) {
       if (acc_dense) vm_wait<(PF - 2) * (STEP_OPS + 1)>();
       else vm_wait<(PF - 2) * STEP_OPS>();
     } else {
@@ -431,7 +468,15 @@ void score_k_kernel(ScoreKArgs a) {
 #if KVQ_TRACE
     stamp(2);
 #endif
-    if (hh + PF - 1 < nh) fetch_head(hh + PF - 1, std::integral_constant<int, nxt>{});
+    // JIT: this head re-loads its own register set for head hh+2, row by row.  EVERY head issues the same JIT_OPS
+    // operations (no conditional definitions of the in-flight registers, constant wait counts): the last two heads
+    // read their own rows once more (never used; just consumed, so the lines are still in the L2)
+    const uint32_t *jit_row = mat_h0 + (int64_t)(hh + 2 < nh ? hh + 2 : hh) * head_words;
+    if constexpr (JIT) {
+      if (hh + 1 < nh) issue_table(hh + 1, nxt);
+    } else {
+      if (hh + PF - 1 < nh) fetch_head(hh + PF - 1, std::integral_constant<int, nxt>{});
+    }
 #if KVQ_TRACE
     stamp(3);
 #endif
@@ -441,18 +486,27 @@ void score_k_kernel(ScoreKArgs a) {
     // accumulators: the LDS pipe needs >= 16 reads in flight per wave to run at rate, and a single
     // accumulator would serialise the FMAs
     f32x2 acc4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    if (wact && !(KVQ_ABL & 64)) {
+    // (JIT: a wave without tokens -- ragged last tile -- decodes its clamped token like the others, so that every wave
+    //  issues the same operations per head; its results are dropped below)
+    if ((wact || JIT) && !(KVQ_ABL & 64)) {
     if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         // even / odd nibbles as bytes = role*128 + code*8
         const uint32_t elo = ((wlo[j] << 3) & 0x78787878u) | rolepat, olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
         const uint32_t ehi = ((whi[j] << 3) & 0x78787878u) | rolepat, ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
-        static_for<0, 2>([&](auto HH) {
-          constexpr int hf = decltype(HH)::value;   // two batches of 4 pairs = 8 look-ups each
+        if constexpr (JIT) {
+          // rows j of the lo / hi halves are consumed: their registers take the same rows of head hh+2
+          asm volatile("" ::"v"(elo), "v"(olo), "v"(ehi), "v"(ohi));
+          asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(wlo[j]) : "v"(woff), "s"(jit_row + j * a.max_len) : "memory");
+          asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(whi[j]) : "v"(woff), "s"(jit_row + hi_words + j * a.max_len) : "memory");
+        }
+        constexpr int LKB = KVQ_K_LKB, NA = KVQ_K_NACC;
+        static_for<0, 8 / LKB>([&](auto HH) {
+          constexpr int hf = decltype(HH)::value;   // batches of LKB pairs = 2 * LKB look-ups each
           f32x2 vl[4], vh[4];
-          static_for<0, 4>([&](auto NN) {
-            constexpr int n = 4 * hf + decltype(NN)::value;
+          static_for<0, LKB>([&](auto NN) {
+            constexpr int n = LKB * hf + decltype(NN)::value;
             constexpr int i = 8 * j + n;
             const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
             const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
@@ -464,15 +518,15 @@ void score_k_kernel(ScoreKArgs a) {
             vh[n & 3] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
 #endif
           });
-          static_for<0, 4>([&](auto NN) {
-            constexpr int n = 4 * hf + decltype(NN)::value;
+          static_for<0, LKB>([&](auto NN) {
+            constexpr int n = LKB * hf + decltype(NN)::value;
             constexpr int i = 8 * j + n;
-            acc4[n & 3] = __builtin_elementwise_fma(cs[i], vl[n & 3], acc4[n & 3]);
-            acc4[(n + 2) & 3] = __builtin_elementwise_fma(cs[i], vh[n & 3], acc4[(n + 2) & 3]);
+            acc4[n & (NA - 1)] = __builtin_elementwise_fma(cs[i], vl[n & 3], acc4[n & (NA - 1)]);
+            acc4[(n + NA / 2) & (NA - 1)] = __builtin_elementwise_fma(cs[i], vh[n & 3], acc4[(n + NA / 2) & (NA - 1)]);
           });
-          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // field extraction (VALU)
-          __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // 8 ds_read_b64
-          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // 8 v_pk_fma_f32
+          __builtin_amdgcn_sched_group_barrier(0x002, 2 * LKB, 0);    // field extraction (VALU)
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * LKB, 0);    // ds_read_b64
+          __builtin_amdgcn_sched_group_barrier(0x002, 2 * LKB, 0);    // v_pk_fma_f32
         });
       });
     } else {
@@ -498,6 +552,10 @@ void score_k_kernel(ScoreKArgs a) {
         });
       });
     }
+      if constexpr (JIT && BITS != 4) {
+        load_words<BITS>(wlo, jit_row, a.max_len, woff);
+        load_words<BITS>(whi, jit_row + hi_words, a.max_len, woff);
+      }
     }   // wact
     const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     float res = acc.x + acc.y;
@@ -514,7 +572,11 @@ void score_k_kernel(ScoreKArgs a) {
       static_assert(!SPARSE || PF == 2 || LATE_Q, "the sparse look-ahead registers are a two-set ring");
       // (when there is nothing left to fetch the set is "defined" by an empty asm instead: both paths then
       // define it in place and hipcc needs no merge copy -- which it would place inside the in-flight window)
-      if constexpr (TRANSPOSED) {
+      if constexpr (JIT) {
+        // entry hh of this lane's token (landed: the wait at the top of this head), then its registers take entry hh+2
+        if (hh < nsteps && !(KVQ_ABL & 128)) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);
+        sparse_fetch_t(hh + 2 < per_t ? hh + 2 : per_t - 1, spv_all[buf & 1], spc_all[buf & 1]);
+      } else if constexpr (TRANSPOSED) {
 #if !KVQ_K_SPARSE_AFTER
         if (nsteps > 0) {
           if (hh + 1 < nsteps) sparse_fetch_t(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);   // waited for by the next head's
@@ -538,10 +600,36 @@ void score_k_kernel(ScoreKArgs a) {
     stamp(5);
 #endif
   };
-  for (int hb = 0; hb < nh; hb += PF) {
-    static_for<0, PF>([&](auto U) {
-      if (hb + decltype(U)::value < nh) head(U, hb + decltype(U)::value);
-    });
+  if constexpr (JIT) {
+    // pairs of heads, then the odd one: no path through the loop skips a head's loads, so the constant wait counts
+    // hold on every control-flow path (which is what tools/check_isa.py verifies on the generated code)
+    int hb = 0;
+    for (; hb + 1 < nh; hb += 2) {
+      head(std::integral_constant<int, 0>{}, hb);
+      head(std::integral_constant<int, 1>{}, hb + 1);
+    }
+    // The last two heads' re-loads are never used, but they ARE in flight: their registers must stay allocated
+    // until they have landed (a dead asm output is a register hipcc re-uses at once).  Wait + keep-alive on each
+    // exit path separately, so that no merge copy of an in-flight register can precede the wait.
+    auto drain = [&]() {
+      vm_wait<0>();
+#pragma unroll
+      for (int i = 0; i < BITS; i++)
+        asm volatile("" ::"v"(wlo_all[0][i]), "v"(whi_all[0][i]), "v"(wlo_all[1][i]), "v"(whi_all[1][i]));
+      asm volatile("" ::"v"(spv_all[0]), "v"(spc_all[0]), "v"(spv_all[1]), "v"(spc_all[1]));
+    };
+    if (hb < nh) {
+      head(std::integral_constant<int, 0>{}, hb);
+      drain();
+    } else {
+      drain();
+    }
+  } else {
+    for (int hb = 0; hb < nh; hb += PF) {
+      static_for<0, PF>([&](auto U) {
+        if (hb + decltype(U)::value < nh) head(U, hb + decltype(U)::value);
+      });
+    }
   }
   if constexpr (SPARSE) {
     // chunks beyond the number of heads of this workgroup (small head groups / wide rows): serial tail
