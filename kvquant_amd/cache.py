@@ -373,11 +373,14 @@ class QuantV(nn.Module):
 
     def vnorm_args(self, prefill=False):
         """Q-Norm argument of the fused V appends: second per-token row table + (scale, offset) + which table the
-        sparse residuals refer to -- the Q-Norm row at 2 bit in decode (ML:1153-1156) and at every width in the
-        prefill glue (ML:1369-1375).  None without Q-Norm."""
+        sparse residuals refer to -- ALWAYS the one the p.V kernel dequantises with (mix_table): the Q-Norm row at
+        2 bit (ML:1153-1156, 1237-1240), the plain row at 3 / 4 bit, in decode and prefill alike.  (The reference's
+        prefill glue reads the zero points from lookup_table2 at every width, ML:1369-1375 -- rows it never writes;
+        taking them from a table the kernel does not read would reconstruct every prompt outlier as
+        x + lut1[z] - lut2[z].)  None without Q-Norm."""
         if not self.norm:
             return (None, 1.0, 0.0, False, True) if self.reference_tie_quirk else None
-        return (self.lookup_table2, self._ns, self._no, prefill or self.bits == 2, self.reference_tie_quirk)
+        return (self.lookup_table2, self._ns, self._no, self.bits == 2, self.reference_tie_quirk)
 
     def mix_table(self):
         """table the p.V kernel dequantises with: the Q-Norm rows at 2 bit (ML:1237-1240)"""
@@ -498,7 +501,7 @@ class QuantV(nn.Module):
                 * sf.unsqueeze(-1) + offset.unsqueeze(-1)
         ops.pack_v_sparse_parallel(self.bits, self.vcache, self.lookup_table, v, minval, maxval, col0)
         zc = ZERO_CODE[self.bits]
-        zp_src = self.lookup_table2 if self.norm else self.lookup_table
+        zp_src = self.mix_table()        # the table the p.V kernel reads (see vnorm_args)
         vals = torch.cat((uv, lv), dim=-1) - zp_src[col0:col0 + S, zc].unsqueeze(-1)
         idx = torch.cat((ui, li), dim=-1)
         idx, order = idx.sort(dim=-1)

@@ -54,10 +54,9 @@
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24
 #endif
-#ifndef KVQ_V_TOUCH
-#define KVQ_V_TOUCH 2   // n > 0: every wave touches its share of the tile rows of chunk ci + n (one 4-byte load per 64-byte
-                        // segment, data discarded) so that they are in the L2 when the chunk's LDS-DMA is issued
-#endif
+#ifndef KVQ_V_PRIO
+#define KVQ_V_PRIO 0    // experiment (measured neutral): wave priority (s_setprio): 1 = high outside the look-up loop (chunk hand-over, sparse phase), low inside;
+#endif                  //  2 = the two workgroups of a CU take turns by chunk parity; 3 = both
 #ifndef KVQ_TRACE
 #define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the chunk loop (tools/dbg/trace_v.py)
 #endif
@@ -436,10 +435,12 @@ template <int BITS, bool FUSED>
 __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   using Cfg = VCfg<BITS>;
   constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT;
-  constexpr bool TOUCH = KVQ_V_TOUCH > 0 && !FUSED;
   __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B + (FUSED ? Cfg::MZ_B : 0) + KVQ_PAD_LDS];  // static: LDS offsets fold into ds immediates
   unsigned char *stage0 = smem;
 
+#if KVQ_V_PRIO & 1
+  __builtin_amdgcn_s_setprio(3);         // (everything outside the look-up loop is a latency chain)
+#endif
   const int tid = threadIdx.x;
   const int ul = tid % Cfg::UW;          // unit within the workgroup
   const int hf = __builtin_amdgcn_readfirstlane((tid / Cfg::UW) % Cfg::HALVES);   // which half of the unit's channels
@@ -728,8 +729,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     };
     stamp(0);
 #endif
-    if constexpr (TOUCH) vm_wait<1>();    // this wave's DMA pieces of chunk ci have landed (the touch issued after them may be in flight)
-    else dma_wait_all();
+    dma_wait_all();                       // this wave's DMA pieces of chunk ci have landed
 #if KVQ_TRACE
     stamp(1);
 #endif
@@ -771,6 +771,15 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       __syncthreads();
     }
     if (KVQ_V_DBG & 1) return;
+#if KVQ_V_PRIO
+    {
+      const int turn = (KVQ_V_PRIO & 2) ? ((ci + ((int)blockIdx.x >= (int)gridDim.x / 2 ? 1 : 0)) & 1) : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      if (turn) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     if constexpr (BITS == 4 && KVQ_V_ASM) {
       constexpr int S0 = Cfg::tile_off(stage);                  // tile
       constexpr int L0 = Cfg::lut_off(stage);                   // codebook rows (row (qq*4+e)*SLOTS + slot)
@@ -1011,43 +1020,21 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     stamp(4);
 #endif
   };
-  // L2 prefetch of the tile rows KVQ_V_TOUCH chunks ahead.  The stage ring has two entries, so a chunk's DMA can only be
-  // issued one chunk ahead and lands late when it has to come from HBM (s_memtime: dma_wait + barrier = 20 % of the
-  // wave).  A touch needs no LDS and no registers: lane g of the workgroup reads 4 bytes of 64-byte segment g of the
-  // chunk's tile rows into a dummy register that is never read, which pulls the line into the L2; the DMA a chunk
-  // later is an L2 hit.  One instruction per wave per chunk, always issued LAST in a chunk, so `s_waitcnt vmcnt(1)` at
-  // the top of the next chunk covers everything but the touch (memory operations return in order).  The dummy register
-  // is threaded through the asm statements as a read-write operand: hipcc keeps it allocated without knowing why.
-  uint32_t touch_reg = 0;
-  const uint32_t *touch_base = a.mat + (int64_t)row_base * a.max_len;
-  uint32_t touch_off;
-  {
-    constexpr int SEG = Cfg::ROWB / 64;                     // 64-byte segments per tile row
-    int gseg = tid < Cfg::ROWS * SEG ? tid : Cfg::ROWS * SEG - 1;
-    int r = gseg / SEG;
-    if (r >= n_rows_valid) r = n_rows_valid - 1;
-    touch_off = (uint32_t)(((int64_t)r * a.max_len) * 4 + (gseg % SEG) * 64);   // < 2^32 (checked by the host)
-  }
-  auto touch = [&](int ci) {
-    if constexpr (TOUCH) {
-      int64_t c0 = t0 + (int64_t)ci * CT;
-      const int64_t lim = (a.max_len < a.L ? a.max_len : a.L) - CT;       // last chunk start that lies inside the rows
-      if (c0 > lim) c0 = lim > 0 ? (lim & ~(int64_t)15) : 0;              // (past the end: a harmless re-touch)
-      asm volatile("global_load_dword %0, %1, %2" : "+v"(touch_reg) : "v"(touch_off), "s"(touch_base + c0) : "memory");
-    }
+  auto hand_over = [&]() {
+#if KVQ_V_PRIO & 1
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(3);       // chunk hand-over (wait, barrier, DMA issue): latency, not throughput
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   };
-  touch(KVQ_V_TOUCH - 1 > 0 ? KVQ_V_TOUCH - 1 : 1);     // (chunk 0 is on its way already; chunk ci + n from chunk ci on)
+  hand_over();
   for (int ci = 0; ci < n_chunks; ci += 2) {
     chunk(std::integral_constant<int, 0>{}, ci);
-    touch(ci + KVQ_V_TOUCH);
+    hand_over();
     if (ci + 1 < n_chunks) {
       chunk(std::integral_constant<int, 1>{}, ci + 1);
-      touch(ci + 1 + KVQ_V_TOUCH);
+      hand_over();
     }
-  }
-  if constexpr (TOUCH) {
-    vm_wait<0>();
-    asm volatile("" ::"v"(touch_reg));
   }
 
   // ---- sum the token slots through LDS (aliases the pipeline stages)

@@ -55,11 +55,18 @@
 #ifndef KVQ_K_JIT
 #define KVQ_K_JIT 1            // mirror variant: packed-word registers are re-loaded for head h+2 as soon as head h has consumed them
 #endif
+#ifndef KVQ_K_PIPE
+#define KVQ_K_PIPE 0           // experiment (measured neutral): 4 bit, look-ups of batch b+1 issued before the FMAs of batch b
+#endif
+#ifndef KVQ_K_PRIO
+#define KVQ_K_PRIO 0           // experiment (measured neutral): wave priority (s_setprio): 1 = high while a wave is
+#endif                         //  in its latency-bound phases (top of the head, outlier step), low in the look-up loop; 2 = the
+                               //  two workgroups of a CU take turns (head parity, second half of the grid inverted); 3 = both
 #ifndef KVQ_K_NACC
 #define KVQ_K_NACC (KVQ_K_JIT ? 2 : 4)   // independent packed accumulators of the dense loop (4 bit)
 #endif
 #ifndef KVQ_K_LKB
-#define KVQ_K_LKB (KVQ_K_JIT ? 2 : 4)    // rotation pairs per look-up batch (4 bit): 2 * LKB ds_read_b64 in flight per wave
+#define KVQ_K_LKB (KVQ_K_PIPE ? 2 : 4)    // rotation pairs per look-up batch (4 bit): 2 * LKB ds_read_b64 in flight per wave
 #endif
 #ifndef KVQ_TRACE
 #define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the head loop (tools/dbg/trace_k.py)
@@ -185,6 +192,22 @@ void score_k_kernel(ScoreKArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if KVQ_TRACE
+  // kernel-level timeline of every wave (100 MHz wall clock, comparable across the chip): entry, loop start, loop
+  // end, exit, + where it ran (HW_ID, XCC_ID); behind the per-head stamps
+  unsigned long long *tl8 = a.trace + (int64_t)1024 * 8 * 32 * 8 + ((int64_t)blockIdx.x * NWAVES + wave) * 8;
+  const bool tlw = lane == 0 && blockIdx.x < 1024;
+  auto tstamp = [&](int k) {
+    unsigned long long rr;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr)::"memory");
+    if (tlw) tl8[k] = rr;
+  };
+  tstamp(0);
+  if (tlw) {
+    tl8[4] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+    tl8[5] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+  }
+#endif
   const int role = lane >> 5;
   const int tl = wave * 32 + (lane & 31);
   // blocks [0, full_blocks): (full tile, head group) pairs; the ragged last tile -- L % T tokens, present on
@@ -480,6 +503,20 @@ void score_k_kernel(ScoreKArgs a) {
 #if KVQ_TRACE
     stamp(3);
 #endif
+#if KVQ_K_PRIO
+    // The SIMD arbitrates between its four waves by priority, then age: with equal priorities the workgroup that was
+    // dispatched first wins every contended issue slot (measured: the first workgroup of a CU finishes its 32 heads in
+    // 63 us, the second in 87 us, and the kernel takes as long as the second).  A wave in the look-up loop is bound by
+    // throughput and does not care when exactly it issues; a wave on the latency chain around it does.
+    {
+      constexpr int lo = 0;
+      const int turn = (KVQ_K_PRIO & 2) ? ((hh + ((int)blockIdx.x >= (int)gridDim.x / 2 ? 1 : 0)) & 1) : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      if (turn) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(lo);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     const unsigned char *tlo = lutq + buf * TAB_B;
     const unsigned char *thi = lutq + buf * TAB_B + KTab<BITS>::HALF_B;
     // 16 look-ups (8 pairs) are issued back to back before their 16 packed FMAs, into 4 independent
@@ -489,7 +526,61 @@ void score_k_kernel(ScoreKArgs a) {
     // (JIT: a wave without tokens -- ragged last tile -- decodes its clamped token like the others, so that every wave
     //  issues the same operations per head; its results are dropped below)
     if ((wact || JIT) && !(KVQ_ABL & 64)) {
-    if constexpr (BITS == 4) {
+    if constexpr (BITS == 4 && KVQ_K_PIPE) {
+      // software pipeline over batches of LKB rotation pairs (2 * LKB look-ups): the look-ups of batch b+1 are on
+      // their way while batch b is accumulated -- a wave that has the LDS to itself is no longer a chain of
+      // extract -> look-up -> wait -> FMA round trips.  sched_barrier(0) pins the order; the wait counts are hipcc's.
+      constexpr int LKB = KVQ_K_LKB, NA = KVQ_K_NACC, NB = 32 / LKB, BPW = 8 / LKB;
+      uint32_t elo = 0, olo = 0, ehi = 0, ohi = 0;
+      f32x2 vl[2][LKB], vh[2][LKB];
+      auto prep = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        // (named here, outside any dependent expression, so that clang captures them)
+        const uint32_t woff_ = woff;
+        const uint32_t *row_lo = jit_row + j * a.max_len, *row_hi = jit_row + hi_words + j * a.max_len;
+        elo = ((wlo[j] << 3) & 0x78787878u) | rolepat;
+        olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
+        ehi = ((whi[j] << 3) & 0x78787878u) | rolepat;
+        ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
+        if (JIT) {   // (a plain `if` on the constant: clang does not capture names that only a discarded branch uses)
+          asm volatile("" ::"v"(elo), "v"(olo), "v"(ehi), "v"(ohi));
+          asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(wlo[j]) : "v"(woff_), "s"(row_lo) : "memory");
+          asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(whi[j]) : "v"(woff_), "s"(row_hi) : "memory");
+        }
+      };
+      auto issue = [&](auto B) {
+        constexpr int b = decltype(B)::value;
+        static_for<0, LKB>([&](auto NN) {
+          constexpr int i = LKB * b + decltype(NN)::value;     // rotation pair
+          constexpr int n = i % 8;
+          const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
+          const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
+          vl[b & 1][decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
+          vh[b & 1][decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+        });
+      };
+      auto accum = [&](auto B) {
+        constexpr int b = decltype(B)::value;
+        static_for<0, LKB>([&](auto NN) {
+          constexpr int nn = decltype(NN)::value;
+          constexpr int i = LKB * b + nn;
+          acc4[i & (NA - 1)] = __builtin_elementwise_fma(cs[i], vl[b & 1][nn], acc4[i & (NA - 1)]);
+          acc4[(i + NA / 2) & (NA - 1)] = __builtin_elementwise_fma(cs[i], vh[b & 1][nn], acc4[(i + NA / 2) & (NA - 1)]);
+        });
+      };
+      prep(std::integral_constant<int, 0>{});
+      issue(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<1, NB>([&](auto B) {
+        constexpr int b = decltype(B)::value;
+        if constexpr (b % BPW == 0) prep(std::integral_constant<int, b / BPW>{});
+        issue(B);
+        __builtin_amdgcn_sched_barrier(0);
+        accum(std::integral_constant<int, b - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      accum(std::integral_constant<int, NB - 1>{});
+    } else if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         // even / odd nibbles as bytes = role*128 + code*8
@@ -569,6 +660,10 @@ void score_k_kernel(ScoreKArgs a) {
       // are written out once after the last head
       if (role == 0 && wact) sc[tl * SCS + ((hh + tl) & (SCS - 1))] += res;
       __builtin_amdgcn_sched_barrier(0);   // keep the sparse chunk's temporaries out of the dense section
+#if KVQ_K_PRIO & 1
+      __builtin_amdgcn_s_setprio(3);       // latency chain: outlier step, loop back-edge, wait, barrier, table DMA
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       static_assert(!SPARSE || PF == 2 || LATE_Q, "the sparse look-ahead registers are a two-set ring");
       // (when there is nothing left to fetch the set is "defined" by an empty asm instead: both paths then
       // define it in place and hipcc needs no merge copy -- which it would place inside the in-flight window)
@@ -600,6 +695,9 @@ void score_k_kernel(ScoreKArgs a) {
     stamp(5);
 #endif
   };
+#if KVQ_TRACE
+  tstamp(1);
+#endif
   if constexpr (JIT) {
     // pairs of heads, then the odd one: no path through the loop skips a head's loads, so the constant wait counts
     // hold on every control-flow path (which is what tools/check_isa.py verifies on the generated code)
@@ -631,6 +729,9 @@ void score_k_kernel(ScoreKArgs a) {
       });
     }
   }
+#if KVQ_TRACE
+  tstamp(2);
+#endif
   if constexpr (SPARSE) {
     // chunks beyond the number of heads of this workgroup (small head groups / wide rows): serial tail
     for (int j = nh; j < nchunks; j++) {
@@ -715,6 +816,9 @@ void score_k_kernel(ScoreKArgs a) {
       }
     }
   }
+#if KVQ_TRACE
+  tstamp(3);
+#endif
 }
 
 static int cu_count() {

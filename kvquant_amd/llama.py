@@ -21,9 +21,20 @@ What carries over from the reference, by name:
     norm / lm_head on the first (ML:2428-2453), activations moved at the split points (ML:2552-2556, 2583-2585);
   * the quantizer pickle: {"model.layers.N.self_attn.k_proj": (upper, lower, [centroids], [normscale, normoffset])}
     (simquant_module_quantizer.py:550-555), keys containing ".lut" skipped (deployment/llama.py:188-189).
-Batch 1, MHA only, as the reference asserts (ML:1408, 1801).  Prefill attention is torch SDPA (the reference calls
-flash-attn there); decode is the GPU-resident kernel path of kvquant_amd.cache.decode_kv.
+Batch 1, MHA only, as the reference asserts (ML:1408, 1801).  Prefill attention is the library's own MFMA flash
+kernel (kvq_prefill_attention; the reference calls flash-attn there, ML:2013-2070); decode is the GPU-resident kernel
+path of kvquant_amd.cache.decode_kv.
+
+Command line = deployment/llama.py:100-216, same positional arguments and flags:
+
+    python -m kvquant_amd.llama <model> <dataset> --abits 4 --include_sparse --sparsity-threshold 0.99 \
+        --first_few_fp16 1 --maxseqlen 4096 --quantizer-path quantizers.pickle --benchmark 128 --check
+
+<dataset> is wikitext2 | ptb | c4 (through `datasets`, as kvquant/datautils.py; needs the hub or a warm cache) or,
+for machines without network, `synthetic` (seeded random token ids) or a path to a saved LongTensor / .npy of token ids.
+`generate()` is the greedy loop of the reference's `generate(..., kvquant=True)` (generation/utils.py:2325-2416).
 """
+import os
 import pickle
 import time
 import types
@@ -206,3 +217,204 @@ def prefill_then_decode(model, input_ids, n_prompt, check=True):
         tot += loss_fn(last.float(), input_ids[:, i]).double()
         last = model(input_ids[:, i:i + 1], use_cache=False).logits[0]
     return {"ppl": float(torch.exp(tot / (n - 1)))} if check else {}
+
+
+# ---- the reference's driver (deployment/llama.py) ------------------------------------------------------------------
+def get_model(model, seqlen, maxseqlen, bits, include_sparse, first_few_fp16):
+    """deployment/llama.py:20-36: config knobs set before the weights are loaded, fp16 weights on the CPU, no
+    initialisation work; `model` is a hub name or a local directory.  Stock transformers (no vendored fork): the
+    compressed KV path is attached afterwards by patch_llama."""
+    import transformers
+
+    def skip(*args, **kwargs):
+        pass
+    torch.nn.init.kaiming_uniform_ = skip
+    torch.nn.init.uniform_ = skip
+    torch.nn.init.normal_ = skip
+    config = transformers.AutoConfig.from_pretrained(model)
+    kvquant_config(config, first_few_fp16=first_few_fp16, maxseqlen=maxseqlen, abits=bits, include_sparse=include_sparse)
+    m = transformers.AutoModelForCausalLM.from_pretrained(model, config=config, torch_dtype=torch.half)
+    m.seqlen = seqlen
+    return m
+
+
+def get_loaders(name, nsamples=128, seed=0, seqlen=2048, model="", vocab_size=32000):
+    """kvquant/datautils.py:get_loaders -> (trainloader [(inp [1, seqlen], tar)], test ids [1, N]).  wikitext2 / ptb / c4
+    as the reference reads them; `synthetic`: seeded uniform token ids (offline machines); a file path: a saved
+    LongTensor (torch.save) or .npy of token ids, cut into nsamples windows the same way (random.seed(seed))."""
+    import random
+    if name in ("wikitext2", "ptb", "c4"):
+        from datasets import load_dataset
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained(model, use_fast=False)
+        if name == "wikitext2":
+            tr = load_dataset("wikitext", "wikitext-2-raw-v1", split="train")
+            te = load_dataset("wikitext", "wikitext-2-raw-v1", split="test")
+            train_ids = tok("\n\n".join(tr["text"]), return_tensors="pt").input_ids
+            test_ids = tok("\n\n".join(te["text"]), return_tensors="pt").input_ids
+        elif name == "ptb":
+            tr = load_dataset("ptb_text_only", "penn_treebank", split="train")
+            te = load_dataset("ptb_text_only", "penn_treebank", split="validation")
+            train_ids = tok("\n\n".join(tr["sentence"]), return_tensors="pt").input_ids
+            test_ids = tok("\n\n".join(te["sentence"]), return_tensors="pt").input_ids
+        else:
+            tr = load_dataset("allenai/c4", data_files={"train": "en/c4-train.00000-of-01024.json.gz"}, split="train")
+            te = load_dataset("allenai/c4", data_files={"validation": "en/c4-validation.00000-of-00008.json.gz"},
+                              split="validation")
+            train_ids = tok(" ".join(tr[:1100]["text"]), return_tensors="pt").input_ids
+            test_ids = tok(" ".join(te[:1100]["text"]), return_tensors="pt").input_ids[:, :256 * seqlen]
+    elif name == "synthetic":
+        g = torch.Generator().manual_seed(seed)
+        train_ids = torch.randint(0, vocab_size, (1, max(4 * seqlen, nsamples * 64 + seqlen + 1)), generator=g)
+        test_ids = torch.randint(0, vocab_size, (1, 8 * seqlen), generator=g)
+    elif os.path.exists(name):
+        if name.endswith(".npy"):
+            import numpy as np
+            ids = torch.from_numpy(np.load(name)).long().reshape(1, -1)
+        else:
+            ids = torch.load(name).long().reshape(1, -1)
+        train_ids = test_ids = ids
+    else:
+        raise ValueError("dataset must be wikitext2, ptb, c4, synthetic or a file of token ids: %r" % name)
+    random.seed(seed)
+    loader = []
+    for _ in range(nsamples):
+        i = random.randint(0, train_ids.shape[1] - seqlen - 1)
+        inp = train_ids[:, i:i + seqlen]
+        tar = inp.clone()
+        tar[:, :-1] = -100
+        loader.append((inp, tar))
+    return loader, test_ids
+
+
+@torch.no_grad()
+def generate(model, input_ids, max_length=None, max_new_tokens=None, eos_token_id=None, pad_token_id=None):
+    """Greedy decoding with the compressed cache: the reference's `model.generate(..., kvquant=True)`
+    (generation/utils.py:2325-2416) -- the prompt goes through the model once (parallel pack of its K / V), then every
+    step feeds ONLY the newest token (`input_ids = next_tokens[:, None]`, :2378-2380), the returned sequence is the
+    prompt with the generated tokens appended, and the loop stops at `max_length` positions (:2401-2406) or once EOS
+    has been produced.  Batch 1."""
+    if input_ids.shape[0] != 1:
+        raise ValueError("the compressed-cache path is batch 1 (ML:1408)")
+    dev = model.gpus[0] if hasattr(model, "gpus") else next(model.parameters()).device
+    input_ids = input_ids.to(dev)
+    n_prompt = input_ids.shape[1]
+    if max_length is None:
+        max_length = n_prompt + (max_new_tokens if max_new_tokens is not None else 20)
+    if eos_token_id is not None and not isinstance(eos_token_id, (list, tuple)):
+        eos_token_id = [eos_token_id]
+    if eos_token_id is not None and pad_token_id is None:
+        raise ValueError("If `eos_token_id` is defined, make sure that `pad_token_id` is defined.")
+    seq = input_ids
+    cur = input_ids
+    unfinished = True
+    pos = n_prompt - 1                   # position of the last token fed so far
+    while True:
+        out = model(cur, use_cache=False)
+        nxt = torch.argmax(out.logits[:, -1, :], dim=-1)
+        if eos_token_id is not None and not unfinished:
+            nxt = torch.full_like(nxt, pad_token_id)
+        seq = torch.cat((seq, nxt[:, None]), dim=-1)
+        cur = nxt[:, None]
+        pos += 1
+        if eos_token_id is not None and int(nxt) in eos_token_id:
+            unfinished = False
+        if not unfinished or seq.shape[1] >= max_length or max_length <= pos + 1:
+            break
+    return seq
+
+
+def main(argv=None):
+    """deployment/llama.py:100-216 (the same arguments); prints what the reference prints."""
+    import argparse
+    import numpy as np
+    ap = argparse.ArgumentParser(prog="python -m kvquant_amd.llama")
+    ap.add_argument("model", type=str, help="llama model to load")
+    ap.add_argument("dataset", type=str, help="wikitext2 | ptb | c4 | synthetic | file of token ids")
+    ap.add_argument("--nsamples", type=int, default=128, help="Number of calibration data samples.")
+    ap.add_argument("--seed", type=int, default=0, help="Seed for sampling the calibration data.")
+    ap.add_argument("--abits", type=int, default=16, choices=[2, 3, 4, 16],
+                    help="#bits to use for quantization; use 16 for evaluating base model.")
+    ap.add_argument("--benchmark", type=int, default=0, help="Number of tokens to use for benchmarking.")
+    ap.add_argument("--check", action="store_true", help="Whether to compute perplexity during benchmarking for verification.")
+    ap.add_argument("--torch_profile", action="store_true", help="Use the torch profiler for timing runs.")
+    ap.add_argument("--seqlen", type=int, default=2048, help="Used by dataloader")
+    ap.add_argument("--maxseqlen", type=int, default=-1, help="Used to set KV cache size")
+    ap.add_argument("--quantizer-path", type=str, help="Path to quantizers.")
+    ap.add_argument("--include_sparse", action="store_true", help="Whether to use dense-and-sparse quantization.")
+    ap.add_argument("--sparsity-threshold", type=float, default=1, help="Outlier percentile.")
+    ap.add_argument("--first_few_fp16", type=int, default=0, help="Store first few tokens separately in fp16")
+    ap.add_argument("--norm", action="store_true", help="Whether to use q-norm.")
+    ap.add_argument("--generate", type=int, default=0, help="(extra) greedy-generate this many tokens after the benchmark prompt")
+    args = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("kvquant_amd.llama needs a GPU (no CPU fallback)")
+    if args.abits != 16 and args.maxseqlen <= 0:
+        raise SystemExit("--maxseqlen must be set: it sizes the preallocated compressed cache")
+    dev = torch.device("cuda:0")
+    model = get_model(args.model, args.seqlen, args.maxseqlen, args.abits if args.abits != 16 else 4,
+                      args.include_sparse, args.first_few_fp16)
+    model.eval()
+    model = model.half()
+    dataloader, _ = get_loaders(args.dataset, nsamples=args.nsamples, seed=args.seed, model=args.model,
+                                seqlen=model.seqlen, vocab_size=model.config.vocab_size)
+    if args.abits != 16:
+        set_devices(model)                       # (ML:2428-2453) before the caches exist: they are created where the layer lives
+        patch_llama(model, sparsity_threshold=args.sparsity_threshold)
+        print("Load quantizers.")
+        load_quantizers(model, args.quantizer_path, args.include_sparse, args.sparsity_threshold, args.norm)
+    else:
+        model.to(dev)
+    if args.benchmark:
+        input_ids = next(iter(dataloader))[0][:, :args.benchmark]
+        print("Benchmarking ...")
+
+        def run():
+            if args.abits == 16:
+                return benchmark_fp16(model, input_ids, check=args.check, verbose=True)
+            return benchmark(model, input_ids, check=args.check, verbose=True)
+        if args.torch_profile:
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU,
+                                                    torch.profiler.ProfilerActivity.CUDA]) as p:
+                res = run()
+            print(p.key_averages().table(sort_by="self_cuda_time_total", row_limit=-1))
+        else:
+            res = run()
+        print("Median:", float(np.median(res["times"])))
+        if args.check:
+            print("PPL:", res["ppl"])
+            print("max memory(MiB):", res["max_memory_mib"])
+        if args.generate and args.abits != 16:
+            seq = generate(model, input_ids[:, -1:], max_new_tokens=args.generate)
+            print("generated:", seq[0, 1:].tolist())
+    return 0
+
+
+@torch.no_grad()
+def benchmark_fp16(model, input_ids, check=False, verbose=False):
+    """--abits 16: the un-patched model, token by token with HF's own fp16 KV cache (the reference's baseline run)"""
+    dev = next(model.parameters()).device
+    input_ids = input_ids.to(dev)
+    loss_fn = nn.CrossEntropyLoss()
+    tot, times, past = 0.0, [], None
+    n = input_ids.numel()
+    for i in range(n):
+        torch.cuda.synchronize()
+        tick = time.time()
+        out = model(input_ids[:, i:i + 1], past_key_values=past, use_cache=True)
+        torch.cuda.synchronize()
+        times.append(time.time() - tick)
+        if verbose:
+            print(i, times[-1])
+        past = out.past_key_values
+        if check and i != n - 1:
+            tot += loss_fn(out.logits[0].float(), input_ids[:, i + 1]).float()
+    res = {"median_s": float(torch.tensor(times).median()), "times": times,
+           "max_memory_mib": torch.cuda.max_memory_allocated() / 1024 / 1024}
+    if check:
+        res["ppl"] = float(torch.exp(tot / (n - 1)))
+    return res
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -487,9 +487,10 @@ def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows,
     with _Dev(mat):
         nbytes = _L().kvq_mix_v_workspace_bytes(bits, 1, H, hd, int(L))
         wsv = _workspace(mat.device, nbytes)
-        probs = None
-        if max_len % 4 != 0 or H > 128:      # the two-pass route inside the library needs room for the probabilities
-            probs = _workspace(mat.device, H * int(L) * 4, slot="probs")
+        # room for the probabilities of the library's two-pass route: always handed over, so that the shapes its
+        # streaming kernel does not take (unaligned rows or tables, H > 128, more than 2^31 packed words, ...) fall back
+        # inside the library whatever its predicate is -- the two checks cannot drift apart (H * L * 4 bytes, cached)
+        probs = _workspace(mat.device, H * int(L) * 4, slot="probs")
         _lib.check(_L().kvq_mix_v_softmax(
             bits, _f(scores, "scores"), parts.data_ptr(), n_parts, float(inv_sqrt_hd),
             None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"),

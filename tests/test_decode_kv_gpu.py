@@ -26,6 +26,48 @@ def test_decode_kv_qnorm(bits, prefill):
 
 
 @pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("fused", [True, False])
+def test_qnorm_prompt_outliers_reconstruct_exactly(bits, fused):
+    """V Q-Norm prefill: the residual of a prompt token's outlier must refer to the table the p.V kernel dequantises
+    with (QuantV.mix_table: lookup_table2 at 2 bit only), so that code + residual gives the value back.  Checked
+    through the kernel itself: p.V on a one-hot probability row returns the token's dequantised vector."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd import ops
+    from kvquant_amd.cache import QuantV
+    from oracle.glue import OracleQuantV
+    dev = torch.device("cuda:0")
+    H, HD, C = decode_check.H, decode_check.HD, decode_check.C
+    S, max_len = 24, 64
+    quant, _, _ = decode_check.quantizer(bits, seed=bits)
+    quant = tuple(quant) + (torch.tensor(1.07), torch.tensor(-0.02))
+    vs = decode_check.util.v_tokens_no_ties(S, Cn=C, seed=70 + bits, k=21).half().float()
+    gv = QuantV(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+                sparsity_threshold=0.99, device=dev)
+    gv.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99, norm=True)
+    vp = vs.t().reshape(H, HD, S).contiguous().to(dev)
+    if fused:
+        gv.parallel_pack(vp)
+    else:
+        uv, ui, lv, li = OracleQuantV.topk_inputs(vs, 0.99, C)
+        gv.parallel_pack(vp, uv.to(dev), ui.to(dev), lv.to(dev), li.to(dev))
+    for t in (0, 7, S - 1):
+        onehot = torch.zeros(1, H, S, device=dev)
+        onehot[:, :, t] = 1.0
+        deq = torch.empty(1, H, HD, device=dev)
+        ops.mix_v(bits, onehot, gv.vcache, deq, gv.mix_table(), S, gv.outliers, gv.outlier_indices, accumulate=False)
+        deq = deq.reshape(-1).cpu()
+        idx = gv.outlier_indices[t].long().cpu()
+        x = vs[t]
+        assert torch.allclose(deq[idx], x[idx], rtol=2e-6, atol=1e-6), (t, (deq[idx] - x[idx]).abs().max())
+        # and the dense channels are codebook values of the same table
+        rest = torch.ones(C, dtype=torch.bool)
+        rest[idx] = False
+        row = gv.mix_table()[t].cpu()
+        assert bool(torch.isin(deq[rest], row).all())
+
+
+@pytest.mark.parametrize("bits", [4, 3, 2])
 def test_fused_prefill_pack_matches_reference_structure(bits):
     """kvq_pack_{k,v}_fused (one launch for the whole prompt) against the reference-structured prefill
     (pack kernel + torch.topk / gather / sort on the GPU): bit for bit."""

@@ -47,3 +47,8 @@ for i, nm in enumerate(names):
 print("wave total %.0f cycles (min %.0f max %.0f)" % (tot.mean(), tot.min(), tot.max()))
 clk = t[..., 12] / t[..., 13] * 100.0
 print("effective shader clock while the kernel runs: %.0f MHz (min %.0f max %.0f); wave lifetime %.1f us" % (clk.mean(), clk.min(), clk.max(), (t[..., 13] / 100.0).mean()))
+# who is slow: the first / second workgroup of a CU (dispatch order: blocks [0, 256) come first), odd / even blocks
+tt = trace.view(512, 8, 16).cpu().double()
+life = tt[..., 13].mean(dim=1) / 100.0
+print("wave lifetime (us): blocks 0..255 mean %.1f, blocks 256..511 mean %.1f; even blocks %.1f, odd blocks %.1f; min %.1f max %.1f"
+      % (life[:256].mean(), life[256:].mean(), life[0::2].mean(), life[1::2].mean(), life.min(), life.max()))

@@ -18,7 +18,7 @@ from kvquant_amd import ops  # noqa: E402
 H, HD, C = 32, 128, 4096
 
 
-def run(bits, L, iters=30, nrot=2):
+def run(bits, L, iters=int(os.environ.get("KB_ITERS", "100")), nrot=2):
     n = 2 ** bits
     W = HD // 32 * bits
     max_len = (L + 64 + 63) // 64 * 64
@@ -64,22 +64,30 @@ def run(bits, L, iters=30, nrot=2):
         ops.mix_v_softmax(bits, s, state["parts"], n_parts, inv, d["v"], out, d["rows"], L, d["vvals"], d["vidx"])
 
     res = {}
+    only = os.environ.get("KB_ONLY", "").split(",") if os.environ.get("KB_ONLY") else None
     for nm, fn, bpt in (("score_k", kcall, C * bits // 8 + 336 + 128), ("softmax_finish", fcall, 256),
                         ("mix_v", vcall, C * bits // 8 + 336 + 4 * n + 128),
                         ("mix_v_softmax", vfcall, C * bits // 8 + 336 + 4 * n + 128)):
-        for i in range(3):
+        if only is not None and nm not in only:
+            if nm == "score_k" or (nm == "softmax_finish" and "mix_v" in only):
+                fn(0)                       # (later kernels read what it leaves behind)
+            continue
+        for i in range(10):
             fn(i)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        # every launch between its own pair of events: the median is robust against clock / power transients
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         for i in range(iters):
+            evs[i][0].record()
             fn(i)
-        e1.record()
+            evs[i][1].record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1000 / iters
+        ts = sorted(a.elapsed_time(b) * 1000 for a, b in evs)
+        us = ts[len(ts) // 2]
         res[nm] = us
-        print("%s bits=%d L=%7d %-15s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)"
-              % (os.environ.get("KVQ_LIB", "libkvq").split("/")[-1], bits, L, nm, us, L * bpt / us / 1e3, L * bpt / us / 1e3 / 80), flush=True)
+        print("%s bits=%d L=%7d %-15s median %8.1f us (min %.1f, p90 %.1f)  %7.1f GB/s (%.1f%% of 8 TB/s)"
+              % (os.environ.get("KVQ_LIB", "libkvq").split("/")[-1], bits, L, nm, us, ts[0], ts[int(len(ts) * 0.9)],
+                 L * bpt / us / 1e3, L * bpt / us / 1e3 / 80), flush=True)
     return res
 
 
