@@ -146,16 +146,46 @@ def layer_step(lay, q, k, v):
 
 
 class KernelTimers:
-    """HIP-event timing of the two matvec launches on the launch stream (torch's
-    current stream is the stream the C ABI is handed)."""
+    """HIP-event timing of the two matvec launches inside the timed region, on the stream they are launched on.
+    decode_kv is ONE library call per layer (kvq_decode_step), so the events are recorded by the library itself
+    (kvq_decode_step_events: before / after the q.K^T launch, before / after the p.V kernel + slab reduce), created
+    and read here through the HIP runtime."""
 
     def __init__(self):
-        self.pairs = {"score_k": [], "mix_v": []}
+        import ctypes
+        self.ct = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.quads = []
+        self.pool = []
+        self.pairs = {"score_k": [], "mix_v": []}      # the five-call path (KVQ_DECODE_MULTICALL=1): torch events
+
+    def _quad(self):
+        ct = self.ct
+        if self.pool:
+            return self.pool.pop()
+        arr = (ct.c_void_p * 4)()
+        for i in range(4):
+            e = ct.c_void_p()
+            if self.hip.hipEventCreate(ct.byref(e)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            arr[i] = e
+        return arr
 
     def install(self):
-        from kvquant_amd import ops
-        self._orig = (ops.score_k_prepared_softmax, ops.mix_v, ops.mix_v_softmax)
-        pairs = self.pairs
+        from kvquant_amd import _lib, ops
+        self._orig = ops.decode_step
+        self._orig_multi = (ops.score_k_prepared_softmax, ops.mix_v, ops.mix_v_softmax)
+        lib = _lib.lib()
+        me = self
+
+        def timed(layer, *a, **kw):
+            q = me._quad()
+            lib.kvq_decode_step_events(q)
+            me.quads.append(q)
+            return me._orig(layer, *a, **kw)
+        ops.decode_step = timed
 
         def wrap(fn, key):
             def inner(*a, **kw):
@@ -164,7 +194,7 @@ class KernelTimers:
                 e0.record()
                 r = fn(*a, **kw)
                 e1.record()
-                pairs[key].append((e0, e1))
+                me.pairs[key].append((e0, e1))
                 return r
             return inner
         ops.score_k_prepared_softmax = wrap(ops.score_k_prepared_softmax, "score_k")   # (+ fused softmax pass 1)
@@ -173,17 +203,28 @@ class KernelTimers:
 
     def uninstall(self):
         from kvquant_amd import ops
-        ops.score_k_prepared_softmax, ops.mix_v, ops.mix_v_softmax = self._orig
+        ops.decode_step = self._orig
+        ops.score_k_prepared_softmax, ops.mix_v, ops.mix_v_softmax = self._orig_multi
 
     def reset(self):
+        torch.cuda.synchronize()
+        self.pool.extend(self.quads)
+        self.quads = []
         for k in self.pairs:
             self.pairs[k].clear()
 
     def mean_us(self, key):
-        p = self.pairs[key]
-        if not p:
-            return None
-        return sum(a.elapsed_time(b) for a, b in p) * 1000.0 / len(p)
+        if not self.quads:
+            p = self.pairs[key]
+            return sum(a.elapsed_time(b) for a, b in p) * 1000.0 / len(p) if p else None
+        a, b = (0, 1) if key == "score_k" else (2, 3)
+        ms = self.ct.c_float()
+        tot = 0.0
+        for q in self.quads:
+            if self.hip.hipEventElapsedTime(self.ct.byref(ms), q[a], q[b]) != 0:
+                raise RuntimeError("hipEventElapsedTime failed")
+            tot += ms.value
+        return tot * 1000.0 / len(self.quads)
 
 
 def algorithmic_bytes(bits, L, kernel):

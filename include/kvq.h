@@ -300,6 +300,60 @@ KVQ_API int kvq_mix_v_softmax(int bits, const float *scores, const float *parts,
                       const float *outliers, const int32_t *outlier_idx, int n_out,
                       int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- one decode token through one layer, one call -------------------------------- */
+
+/* The buffers of one layer's compressed KV cache: what the reference keeps as attributes of QuantK / QuantV
+ * (modeling_llama.py:352-1385) plus the token-contiguous K outlier mirror.  Dense-and-Sparse caches
+ * (include_sparse) only; thr_k = outliers per side and token (21 at 1 % of 4096 channels). */
+typedef struct kvq_layer {
+  int bits, H, hd, thr_k;
+  int64_t max_len;
+  float rope_theta;
+  int pos_offset;             /* first_few_fp16: position of cached token 0 */
+  /* K (QuantK) */
+  int32_t *kmat;              /* kcache       int32 [H][hd/32*bits][max_len] */
+  const float *klut;          /* lookup_table f32 [H][hd][2^bits] (pack) */
+  const float *klut_off;      /* table the outlier residuals refer to (lookup_table2 with Q-Norm, else klut) */
+  const float *klo, *khi;     /* outlier_threshold_lower / _upper f32 [H*hd] */
+  float *koutliers;           /* [max_len][2*thr_k] */
+  int32_t *kidx;
+  float *koutliers_t;         /* mirror [2*thr_k][max_len] */
+  int32_t *kidx_t;
+  const float *klut_ends;     /* optional [H*hd][2] */
+  const float *klut_score;    /* optional: table the scores dequantise with (Q-Norm at 2 bit), NULL = klut */
+  /* V (QuantV) */
+  int32_t *vmat;              /* vcache */
+  float *vlut_rows;           /* lookup_table f32 [max_len][2^bits] */
+  const float *vlut_sorted;   /* lut f32 [2^bits], ascending */
+  float *voutliers;           /* [max_len][2*thr_k] */
+  int32_t *vidx;
+  const kvq_vopts *vnorm;     /* optional */
+  const float *v_mix_rows;    /* optional: table p.V dequantises with (lookup_table2 at 2 bit with Q-Norm), NULL = vlut_rows */
+} kvq_layer;
+
+/* One decode token through one layer: K / V fused appends at column kcol (= vcol) + query tables, q.K^T with RoPE +
+ * outliers + first softmax pass, softmax, p.V + outliers, slab reduce -- the launches of kvq_decode_prologue,
+ * kvq_score_k_prepared_softmax, kvq_softmax_finish (or, fuse_softmax != 0: inside kvq_mix_v_softmax) and kvq_mix_v
+ * issued back to back on `stream` from one call.  Replaces the decode branch of the patched LlamaAttention.forward
+ * around QuantK / QuantV.forward_fused_sparse (modeling_llama.py:1930-2000).  q [H][128] (RoPE'd), k, v [H*hd]:
+ * all fp32 or all fp16.  sinks / v_sink / sink_probs: the fp16 attention-sink tokens (as kvq_decode_prologue /
+ * kvq_softmax_finish), or NULL.  out f32 [H][hd]: the complete attention output.  Scores, probabilities, partials and
+ * slabs live in `workspace` (kvq_decode_step_workspace_bytes(bits, H, hd, L) with L = kcol + 1; 256-byte aligned). */
+KVQ_API size_t kvq_decode_step_workspace_bytes(int bits, int H, int hd, int64_t L);
+KVQ_API int kvq_decode_step(const kvq_layer *layer, int64_t kcol, int64_t vcol, const void *q, const void *k,
+                    const void *v, int acts_are_half, const kvq_sinks *sinks, const uint16_t *v_sink,
+                    uint16_t *sink_probs, float *out, int fuse_softmax, void *workspace, size_t workspace_bytes,
+                    void *stream);
+/* measurement hook: events4 = four hipEvent_t (or NULL entries) recorded on the stream before / after the q.K^T launch
+ * and before / after the p.V launches (p.V kernel + slab reduce; with fuse_softmax the merged kernel) of the NEXT
+ * kvq_decode_step on this thread; the hook clears itself after that call.  NULL: no events. */
+KVQ_API int kvq_decode_step_events(void *const *events4);
+/* the same for a stack of layers that follow each other without other work in between (all at the same column;
+ * q / k / v / out: arrays of n_layers pointers; one workspace, reused layer after layer) */
+KVQ_API int kvq_decode_steps(int n_layers, const kvq_layer *layers, int64_t col, const void *const *q,
+                     const void *const *k, const void *const *v, int acts_are_half, float *const *out,
+                     int fuse_softmax, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- prefill attention (the MFMA path of BASELINE config 4) ----------------------- */
 
 /* Causal self-attention of the S prompt tokens of one sequence, all heads, flash-style on the gfx950 matrix cores

@@ -29,6 +29,22 @@ class Sinks(ctypes.Structure):
 
 _sk = ctypes.POINTER(Sinks)
 
+
+class Layer(ctypes.Structure):
+    """struct kvq_layer of include/kvq.h"""
+    _fields_ = [("bits", ctypes.c_int), ("H", ctypes.c_int), ("hd", ctypes.c_int), ("thr_k", ctypes.c_int),
+                ("max_len", ctypes.c_int64), ("rope_theta", ctypes.c_float), ("pos_offset", ctypes.c_int),
+                ("kmat", ctypes.c_void_p), ("klut", ctypes.c_void_p), ("klut_off", ctypes.c_void_p),
+                ("klo", ctypes.c_void_p), ("khi", ctypes.c_void_p), ("koutliers", ctypes.c_void_p),
+                ("kidx", ctypes.c_void_p), ("koutliers_t", ctypes.c_void_p), ("kidx_t", ctypes.c_void_p),
+                ("klut_ends", ctypes.c_void_p), ("klut_score", ctypes.c_void_p),
+                ("vmat", ctypes.c_void_p), ("vlut_rows", ctypes.c_void_p), ("vlut_sorted", ctypes.c_void_p),
+                ("voutliers", ctypes.c_void_p), ("vidx", ctypes.c_void_p), ("vnorm", ctypes.POINTER(VNorm)),
+                ("v_mix_rows", ctypes.c_void_p)]
+
+
+_ly = ctypes.POINTER(Layer)
+
 # name -> (restype, argtypes); mirrors include/kvq.h one to one
 SIGNATURES = {
     "kvq_version": (_i, []),
@@ -60,6 +76,10 @@ SIGNATURES = {
     "kvq_softmax_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp]),
     "kvq_mix_v_softmax": (_i, [_i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp, _vp, _i,
                                _i, _vp, _sz, _vp]),
+    "kvq_decode_step_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
+    "kvq_decode_step": (_i, [_ly, _i64, _i64, _vp, _vp, _vp, _i, _sk, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "kvq_decode_step_events": (_i, [_vp]),
+    "kvq_decode_steps": (_i, [_i, _ly, _i64, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "kvq_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "kvq_append_k_sparse_orig": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "kvq_append_v_sparse_orig": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),

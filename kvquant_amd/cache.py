@@ -153,6 +153,7 @@ class QuantK(nn.Module):
         self.lut_ends = torch.stack((t_off[..., 0], t_off[..., -1]), dim=-1).reshape(-1, 2).contiguous()
         self.outlier_threshold_upper = up16.float().contiguous()
         self.outlier_threshold_lower = lo16.float().contiguous()
+        self._step_layer = None          # (cached kvq_layer of decode_kv: the tables just moved)
 
     # -- host glue kept on the GPU ------------------------------------------------
     def _outlier_rows(self, k_tok_major, resc_tok_major):
@@ -321,11 +322,14 @@ class QuantV(nn.Module):
         self.first_few_fp16 = first_few_fp16
         self.norm = False
         self.lookup_table2 = None
-        # The reference clips a value to the zero-point code only STRICTLY outside its per-token thresholds while
-        # storing the 21 largest / smallest as residuals: a selected value that EQUALS the threshold (21st == 22nd
-        # largest, ~10 % of fp16 tokens) is dequantised twice.  The GPU-resident appends clip
-        # exactly the stored values, like the reference's simulated path; True replicates the double count.
-        self.reference_tie_quirk = False
+        # The reference's kernel clips a value to the zero-point code only STRICTLY outside its per-token thresholds
+        # (KCU:2084) while its glue stores the 21 largest / smallest as residuals (ML:1093-1096): a selected value that
+        # EQUALS the threshold (21st == 22nd largest, ~10 % of fp16 tokens) keeps its own code AND gets a residual, i.e.
+        # is dequantised twice.  Default True: the GPU-resident appends pack exactly the codes of the
+        # reference's CUDA path on every token, ties included (tests/test_ties_gpu.py runs them next to the reference's
+        # own kernel).  False: clip exactly the stored values -- the semantics of the reference's SIMULATED path
+        # (SQ:95-108), whose reconstruction of such a value is exact; differs from the CUDA path in one code per tie.
+        self.reference_tie_quirk = True
 
     @property
     def device(self):
@@ -361,6 +365,7 @@ class QuantV(nn.Module):
         else:
             self.normscale = self.normoffset = None
             self.lookup_table2 = None
+        self._tables_version = getattr(self, "_tables_version", 0) + 1
 
     def topk_inputs(self, v_tok_major):
         """The four tensors the reference's attention hands over (ML:1537-1545 on the
@@ -511,6 +516,7 @@ class QuantV(nn.Module):
         self.vlen += S
 
 
+ONE_CALL_PER_LAYER = os.environ.get("KVQ_DECODE_MULTICALL", "0") != "1"   # (env: A/B runs against the five-call path)
 FUSE_SOFTMAX_INTO_MIX_V = False
 # ... except for short caches, where a launch less is worth more than the second conversion (env: A/B runs)
 FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", "32768"))
@@ -545,6 +551,23 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
             raise ValueError("pass either sink_scores or (k_sink, v_sink)")
         sink_scores = torch.empty((kc.num_heads, k_sink.shape[2]), dtype=torch.float16, device=kc.device)
         sinks = (k_sink, sink_scores, inv)
+    H = kc.num_heads
+    if ONE_CALL_PER_LAYER and kpos == vpos and (sink_scores is None or sinks is not None):
+        # the whole launch sequence from one library call (kvq_decode_step): the five Python / ctypes round trips of
+        # the path below cost ~78 us of host time per layer, as much as the GPU needs for a 4K-token cache
+        key = (id(vc), getattr(vc, "_tables_version", 0), vc.reference_tie_quirk, vc.norm, kc.norm)
+        cached = getattr(kc, "_step_layer", None)
+        if cached is None or cached[0] != key:
+            cached = (key,) + ops.make_layer(kc, vc, table, lut_off)
+            kc._step_layer = cached
+        out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
+        sink_probs = None if sinks is None else torch.empty_like(sink_scores)
+        L = kpos + 1
+        ops.decode_step(cached[1], kpos, q, k, v, out, FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO, sinks, v_sink,
+                        sink_probs)
+        kc.klen += 1
+        vc.vlen += 1
+        return out, sink_probs
     ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
                              kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
                              vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
@@ -553,7 +576,6 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
     kc.klen += 1
     vc.vlen += 1
     L = kc.klen - kc.first_few_fp16
-    H = kc.num_heads
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
     out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
     if FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO:

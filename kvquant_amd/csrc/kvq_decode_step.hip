@@ -1,0 +1,129 @@
+// kvq_decode_step: one decode token through ONE layer's compressed KV path in a single call -- the launch sequence
+// of kvquant_amd.cache.decode_kv (prologue -> q.K^T + softmax partials -> softmax finish -> p.V -> slab reduce, or
+// the 4-launch form with the softmax inside the p.V kernel for short caches) issued from C++ instead of from five
+// Python / ctypes round trips.  What it replaces in the reference: the per-token body of the patched
+// LlamaAttention.forward around QuantK.forward_fused_sparse / QuantV.forward_fused_sparse (ML:1930-2000), i.e. ~25
+// torch launches, two host top-k round trips and a side stream per layer.
+//
+// Why a call and not a hipGraph: every launch depends on the cache length (grid sizes, partial counts, append
+// column), so a captured graph would have to be re-parameterised every token; the boundary between two dependent
+// kernels costs the same eager or replayed (MI355X_MICROARCH.md price list: "boundary ... eager == hipGraph"), and
+// what made short contexts host-bound was the ~78 us of interpreter time per layer, not the launches themselves
+// (~4 us each from C++).  kvq_decode_steps takes a whole stack of layers for callers whose layers follow each other
+// without other work in between (the KV-path benchmark).
+#include "kvq_common.h"
+#include "kvq_host.h"
+
+namespace kvq {
+
+struct StepPlan {
+  size_t score_ws, parts_off, parts_b, mix_off, mix_b, scores_off, scores_b, probs_off, probs_b, total;
+  int n_parts;
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static StepPlan plan_step(int bits, int H, int hd, int64_t L) {
+  StepPlan p;
+  p.score_ws = align256(kvq_score_k_workspace_bytes(bits, 1, H));
+  p.n_parts = kvq_score_k_softmax_parts(bits, L, 1);
+  p.parts_off = p.score_ws;
+  p.parts_b = align256((size_t)H * (p.n_parts > 0 ? p.n_parts : 1) * 8);
+  p.mix_off = p.parts_off + p.parts_b;
+  p.mix_b = align256(kvq_mix_v_workspace_bytes(bits, 1, H, hd, L));
+  p.scores_off = p.mix_off + p.mix_b;
+  p.scores_b = align256((size_t)H * L * 4);
+  p.probs_off = p.scores_off + p.scores_b;
+  p.probs_b = p.scores_b;
+  p.total = p.probs_off + p.probs_b;
+  return p;
+}
+
+// measurement hook: events recorded around the two matvec launches of the next kvq_decode_step on this thread
+static thread_local hipEvent_t *step_events = nullptr;
+
+static void record(int i, hipStream_t st) {
+  if (step_events && step_events[i]) (void)hipEventRecord(step_events[i], st);
+}
+
+}  // namespace kvq
+
+using namespace kvq;
+
+extern "C" {
+
+int kvq_decode_step_events(void *const *events4) {
+  step_events = reinterpret_cast<hipEvent_t *>(const_cast<void **>(events4));
+  return KVQ_OK;
+}
+
+size_t kvq_decode_step_workspace_bytes(int bits, int H, int hd, int64_t L) {
+  if (bits < 2 || bits > 4 || H <= 0 || hd != kHeadDim || L <= 0) return 0;
+  return plan_step(bits, H, hd, L).total;
+}
+
+int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void *q, const void *k, const void *v,
+                    int acts_are_half, const kvq_sinks *sinks, const uint16_t *v_sink, uint16_t *sink_probs,
+                    float *out, int fuse_softmax, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!ly || !q || !k || !v || !out || kcol < 0 || vcol != kcol) return KVQ_EINVAL;
+  if (!ly->koutliers || !ly->voutliers || !ly->koutliers_t || !ly->kidx_t) return KVQ_EINVAL;   // Dense-and-Sparse caches with the mirror
+  if (v_sink && (!sinks || !sink_probs)) return KVQ_EINVAL;
+  const int bits = ly->bits, H = ly->H, hd = ly->hd;
+  const int64_t L = kcol + 1;                       // cached tokens after the append (sink tokens not counted)
+  if (L > ly->max_len) return KVQ_EINVAL;
+  const StepPlan p = plan_step(bits, H, hd, L);
+  if (p.n_parts <= 0) return KVQ_EINVAL;
+  if (!workspace || workspace_bytes < p.total || reinterpret_cast<uintptr_t>(workspace) % 256) return KVQ_EWORKSPACE;
+  unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+  float *parts = reinterpret_cast<float *>(ws + p.parts_off);
+  float *scores = reinterpret_cast<float *>(ws + p.scores_off);
+  float *probs = reinterpret_cast<float *>(ws + p.probs_off);
+  const int n_out = 2 * ly->thr_k;
+  const int n_sink = sinks ? sinks->n_sink : 0;
+  const float inv = 1.0f / sqrtf((float)hd);
+  const float *ktab = ly->klut_score ? ly->klut_score : ly->klut;
+  int rc = kvq_decode_prologue(bits, ly->kmat, ly->klut, ly->klut_off, k, ly->klo, ly->khi, ly->koutliers, ly->kidx, kcol,
+                               ly->vmat, ly->vlut_rows, ly->vlut_sorted, v, ly->voutliers, ly->vidx, vcol, q,
+                               acts_are_half, ly->thr_k, H, hd, ly->max_len, ly->koutliers_t, ly->kidx_t, ly->klut_ends,
+                               ly->klut_score, ly->vnorm, sinks, ws, p.score_ws, stream);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  struct Clear { ~Clear() { step_events = nullptr; } } clear_events_on_exit;
+  record(0, st);
+  rc = kvq_score_k_prepared_softmax(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta, ly->pos_offset,
+                                    ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws, p.score_ws, inv,
+                                    parts, p.n_parts, stream);
+  record(1, st);
+  if (rc) return rc;
+  const float *vrows = ly->v_mix_rows ? ly->v_mix_rows : ly->vlut_rows;
+  const uint16_t *sink_scores = sinks ? sinks->sink_scores : nullptr;
+  if (fuse_softmax) {
+    record(2, st);
+    rc = kvq_mix_v_softmax(bits, scores, parts, p.n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs, ly->vmat,
+                           out, vrows, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0, ws + p.mix_off, p.mix_b,
+                           stream);
+    record(3, st);
+    return rc;
+  }
+  rc = kvq_softmax_finish(scores, sink_scores, parts, p.n_parts, probs, sink_probs, H, L, n_sink, inv, v_sink, out, stream);
+  if (rc) return rc;
+  record(2, st);
+  rc = kvq_mix_v(bits, probs, ly->vmat, out, vrows, 1, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out,
+                 v_sink ? 1 : 0, ws + p.mix_off, p.mix_b, stream);
+  record(3, st);
+  return rc;
+}
+
+int kvq_decode_steps(int n_layers, const kvq_layer *layers, int64_t col, const void *const *q, const void *const *k,
+                     const void *const *v, int acts_are_half, float *const *out, int fuse_softmax, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+  if (n_layers <= 0 || !layers || !q || !k || !v || !out) return KVQ_EINVAL;
+  for (int i = 0; i < n_layers; i++) {
+    int rc = kvq_decode_step(&layers[i], col, col, q[i], k[i], v[i], acts_are_half, nullptr, nullptr, nullptr, out[i],
+                             fuse_softmax, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return KVQ_OK;
+}
+
+}  // extern "C"

@@ -16,6 +16,10 @@
 
 #include <cstdlib>
 
+#ifndef KVQ_PACK_TILED
+#define KVQ_PACK_TILED 1     // prefill pack: four tokens per workgroup, the prompt read once (kvq_pack_tiled.h); 0: the
+#endif                       // per-token workgroups (A/B runs)
+
 namespace kvq {
 
 constexpr int kSelThreads = 1024;
@@ -411,6 +415,10 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   KVQ_STAMP(A, 6);
 }
 
+}  // namespace kvq
+#include "kvq_pack_tiled.h"
+namespace kvq {
+
 template <int BITS, bool IS_V>
 __global__ __launch_bounds__(kSelThreads) void fused_append_kernel(AppendArgs A) {
   fused_append_body<BITS, IS_V>(A);
@@ -616,6 +624,7 @@ static int launch_pack(bool is_v, int bits, AppendArgs a, int H, int hd, int64_t
   int rc = check_append(is_v, a, H, hd);
   if (rc) return rc;
   a.x_stride = S;
+  if (KVQ_PACK_TILED && !a.codes_elsewhere && pack_tiled_ok(a, S)) return launch_pack_tiled(is_v, bits, a, S, st);
   if (a.C <= kPackThreads * kPackPerLane) return launch_pack_nt<kPackThreads, kPackPerLane>(is_v, bits, a, S, st);
   return launch_pack_nt<kSelThreads, kMaxPerLane>(is_v, bits, a, S, st);
 }
@@ -649,6 +658,9 @@ int kvq_pack_k_fused(int bits, int32_t *mat, const float *lut, const float *lut_
   // codes + pack kernel (codebook rows amortised over 256 tokens): 0.57 -> see DESIGN.md ms at S = 8192
   AppendArgs a = k_args(mat, lut, lut_off, x, 0, lo, hi, outliers, outlier_idx, thr_k, H, hd, max_len, col0,
                         outliers_t, outlier_idx_t);
+  a.x_stride = S;
+  if (KVQ_PACK_TILED && S > 0 && col0 + S <= max_len && check_append(false, a, H, hd) == KVQ_OK && pack_tiled_ok(a, S))
+    return launch_pack_tiled(false, bits, a, S, (hipStream_t)stream);   // one pass: selection, rows AND codes
   a.codes_elsewhere = 1;
   int rc = launch_pack(false, bits, a, H, hd, S, (hipStream_t)stream);
   if (rc) return rc;

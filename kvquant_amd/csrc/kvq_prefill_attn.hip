@@ -48,10 +48,12 @@ struct AttnArgs {
   float scale_log2e;      // softmax scale * log2(e)
 };
 
+// two floats -> packed fp16, ROUND TO NEAREST (gfx950's v_cvt_pk_f16_f32; cvt_pkrtz truncates, which biases P -- and
+// with it every output -- down by 2^-12 .. 2^-11 relative to the unrounded row sum it is normalised with)
 __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
-  typedef __fp16 h2 __attribute__((ext_vector_type(2)));
-  h2 r = __builtin_amdgcn_cvt_pkrtz(a, b);
-  return __builtin_bit_cast(uint32_t, r);
+  uint32_t r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 __global__ __launch_bounds__(kAW * 64, kAW == 8 ? 2 : 2) void prefill_attn_kernel(AttnArgs a) {

@@ -58,6 +58,10 @@
 #ifndef KVQ_K_PIPE
 #define KVQ_K_PIPE 0           // experiment (measured neutral): 4 bit, look-ups of batch b+1 issued before the FMAs of batch b
 #endif
+#ifndef KVQ_K_WEAVE
+#define KVQ_K_WEAVE 0          // 4 bit, mirror variant: the latency chains of a head iteration -- next table's DMA issue, the outlier
+#endif                         //  entry (angle shuffle, sincos, q look-ups, pair merge, score-tile update) -- are cut into
+                               //  pieces and issued between the look-up batches of the dense section instead of after it
 #ifndef KVQ_K_PRIO
 #define KVQ_K_PRIO 0           // experiment (measured neutral): wave priority (s_setprio): 1 = high while a wave is
 #endif                         //  in its latency-bound phases (top of the head, outlier step), low in the look-up loop; 2 = the
@@ -66,7 +70,7 @@
 #define KVQ_K_NACC (KVQ_K_JIT ? 2 : 4)   // independent packed accumulators of the dense loop (4 bit)
 #endif
 #ifndef KVQ_K_LKB
-#define KVQ_K_LKB (KVQ_K_PIPE ? 2 : 4)    // rotation pairs per look-up batch (4 bit): 2 * LKB ds_read_b64 in flight per wave
+#define KVQ_K_LKB ((KVQ_K_PIPE || KVQ_K_WEAVE) ? 2 : 4)    // rotation pairs per look-up batch (4 bit): 2 * LKB ds_read_b64 in flight per wave
 #endif
 #ifndef KVQ_TRACE
 #define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the head loop (tools/dbg/trace_k.py)
@@ -174,7 +178,9 @@ void score_k_kernel(ScoreKArgs a) {
   // the JIT_OPS operations issued during head h -- covers exactly what head h+1 needs: its table (issued at the top
   // of head h), its words and its outlier entry (issued during head h-1).
   constexpr bool JIT = KVQ_K_JIT && TRANSPOSED && !KVQ_K_SPARSE_AFTER && PF == 2;
-  constexpr int JIT_OPS = 2 * BITS + 2;
+  constexpr bool WEAVE = KVQ_K_WEAVE && JIT && BITS == 4;
+  // (WEAVE: the table pieces are issued behind the first two word re-loads of the head)
+  constexpr int JIT_OPS = 2 * BITS + 2 - (WEAVE ? 2 : 0);
   // VMEM operations of one look-ahead step that EVERY wave issues (waves with an extra table piece wait
   // for one more than they need to)
   constexpr int STEP_OPS = 2 * BITS + TAB_DMA / NWAVES;
@@ -476,6 +482,12 @@ void score_k_kernel(ScoreKArgs a) {
     // this head's table and words were requested PF-1 heads ago; younger requests may stay in flight
     if constexpr (JIT) {
       vm_wait<JIT_OPS>();   // (what head hh-1 issued for head hh+1 may stay in flight)
+      // the set this head consumes exists from HERE on: an empty read-write asm makes the registers opaque at this
+      // point, so that no use of them can be scheduled above the wait (a "memory" clobber orders memory operations,
+      // not register-only instructions -- cdna_hip_programming.md 5.7 item 3)
+#pragma unroll
+      for (int i = 0; i < BITS; i++) asm volatile("" : "+v"(wlo_all[buf][i]), "+v"(whi_all[buf][i]));
+      asm volatile("" : "+v"(spv_all[buf & 1]), "+v"(spc_all[buf & 1]));
     } else if (PF > 2 && hh + 1 < nh) {
       if (acc_dense) vm_wait<(PF - 2) * (STEP_OPS + 1)>();
       else vm_wait<(PF - 2) * STEP_OPS>();
@@ -495,7 +507,9 @@ void score_k_kernel(ScoreKArgs a) {
     // operations (no conditional definitions of the in-flight registers, constant wait counts): the last two heads
     // read their own rows once more (never used; just consumed, so the lines are still in the L2)
     const uint32_t *jit_row = mat_h0 + (int64_t)(hh + 2 < nh ? hh + 2 : hh) * head_words;
-    if constexpr (JIT) {
+    if constexpr (WEAVE) {
+      // (woven into the dense section below)
+    } else if constexpr (JIT) {
       if (hh + 1 < nh) issue_table(hh + 1, nxt);
     } else {
       if (hh + PF - 1 < nh) fetch_head(hh + PF - 1, std::integral_constant<int, nxt>{});
@@ -526,7 +540,109 @@ void score_k_kernel(ScoreKArgs a) {
     // (JIT: a wave without tokens -- ragged last tile -- decodes its clamped token like the others, so that every wave
     //  issues the same operations per head; its results are dropped below)
     if ((wact || JIT) && !(KVQ_ABL & 64)) {
-    if constexpr (BITS == 4 && KVQ_K_PIPE) {
+    if constexpr (WEAVE) {
+      // Look-up batches of LKB rotation pairs; while a batch's look-ups travel, ONE piece of the head's latency chains
+      // is issued: its instructions are independent of the batch, their own round trips (LDS shuffles and reads, the
+      // DMA issue) overlap with the following batches.  sched_barrier(0) pins the order, the wait counts are hipcc's.
+      constexpr int LKB = KVQ_K_LKB, NA = KVQ_K_NACC, NB = 32 / LKB, BPW = 8 / LKB;
+      uint32_t elo = 0, olo = 0, ehi = 0, ohi = 0;
+      f32x2 vl[LKB], vh[LKB];
+      auto prep = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const uint32_t woff_ = woff;
+        const uint32_t *row_lo = jit_row + j * a.max_len, *row_hi = jit_row + hi_words + j * a.max_len;
+        elo = ((wlo[j] << 3) & 0x78787878u) | rolepat;
+        olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
+        ehi = ((whi[j] << 3) & 0x78787878u) | rolepat;
+        ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
+        asm volatile("" ::"v"(elo), "v"(olo), "v"(ehi), "v"(ohi));
+        asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(wlo[j]) : "v"(woff_), "s"(row_lo) : "memory");
+        asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(whi[j]) : "v"(woff_), "s"(row_hi) : "memory");
+      };
+      auto issue = [&](auto B) {
+        constexpr int b = decltype(B)::value;
+        static_for<0, LKB>([&](auto NN) {
+          constexpr int i = LKB * b + decltype(NN)::value;
+          constexpr int n = i % 8;
+          const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
+          const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
+          vl[decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
+          vh[decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+        });
+      };
+      auto accum = [&](auto B) {
+        constexpr int b = decltype(B)::value;
+        static_for<0, LKB>([&](auto NN) {
+          constexpr int nn = decltype(NN)::value;
+          constexpr int i = LKB * b + nn;
+          acc4[i & (NA - 1)] = __builtin_elementwise_fma(cs[i], vl[nn], acc4[i & (NA - 1)]);
+          acc4[(i + NA / 2) & (NA - 1)] = __builtin_elementwise_fma(cs[i], vh[nn], acc4[(i + NA / 2) & (NA - 1)]);
+        });
+      };
+      // ---- the outlier entry of this head (sparse_step_t, cut into stages) -------------------------------------------
+      const bool sp_on = hh < nsteps && !(KVQ_ABL & 128);          // (wave-uniform)
+      const float sp_val = spv_all[buf & 1];
+      const int sp_col = spc_all[buf & 1];
+      const int sp_hhE = (sp_col >> 7) - h0, sp_ch = sp_col & 127;
+      bool sp_use = false;
+      float sp_th = 0.f, sp_q1 = 0.f, sp_q2 = 0.f, sp_sn = 0.f, sp_c = 0.f, sp_x = 0.f, sp_xo = 0.f, sp_old = 0.f;
+      int sp_hk = 0, sp_ho = 0;
+      float *sp_cell = sc;
+      auto piece = [&](auto P) {
+        constexpr int p = decltype(P)::value;
+        if constexpr (p == 0) {
+          if (hh + 1 < nh) issue_table(hh + 1, nxt);
+        } else if constexpr (p == 1) {
+          // (no branches in here: the stages run for every lane, `sp_use` decides at the end -- control flow inside the
+          //  dense section splits it into blocks and the register allocation falls apart)
+          const bool s_ok = !(role == 1 && (a.n_out & 1) && hh == 0);
+          sp_use = sp_on && valid && s_ok && (sp_val != 0.f) && ((unsigned)sp_hhE < (unsigned)nh);
+          sp_th = theta_of(sp_ch & 63);
+          const int hq = sp_use ? sp_hhE : 0;
+          sp_q1 = ql[hq * kHeadDim + sp_ch];
+          sp_q2 = ql[hq * kHeadDim + (sp_ch ^ 64)];
+        } else if constexpr (p == 2) {
+          sincos_rev(sp_th * posf, sp_sn, sp_c);
+        } else if constexpr (p == 3) {
+          const float sg = (sp_ch < 64) ? sp_sn : -sp_sn;
+          sp_x = sp_use ? sp_val * fmaf(sp_c, sp_q1, sg * sp_q2) : 0.f;
+          sp_hk = sp_use ? sp_hhE : (-1 - role);
+          sp_ho = __shfl_xor(sp_hk, 32);
+          sp_xo = __shfl_xor(sp_x, 32);
+        } else if constexpr (p == 4) {
+          const bool same = sp_ho == sp_hk;
+          sp_x += (same && role == 0) ? sp_xo : 0.f;
+          sp_use = sp_use && !(same && role != 0);
+          const int hcell = sp_use ? sp_hhE : 0;
+          sp_cell = sc + tl * SCS + ((hcell + tl) & (SCS - 1));
+          sp_old = *sp_cell;
+        } else if constexpr (p == 5) {
+          // predicated store WITHOUT control flow (a branch in here splits the section and the register allocation falls
+          // apart): exec is narrowed to the lanes with a live entry inside one asm statement.  An unused lane must not
+          // write at all -- its partner lane may be updating that very cell.
+          {
+            const unsigned long long live = __builtin_amdgcn_ballot_w64(sp_use);
+            const uint32_t addr = lds_addr(sp_cell);
+            const float nv = sp_old + sp_x;
+            unsigned long long keep;
+            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
+                         : "=&s"(keep) : "v"(addr), "v"(nv), "s"(live) : "memory");
+          }
+          // ... and its registers take entry hh+2 (see the sparse part of the unwoven path)
+          sparse_fetch_t(hh + 2 < per_t ? hh + 2 : per_t - 1, spv_all[buf & 1], spc_all[buf & 1]);
+        }
+      };
+      static_for<0, NB>([&](auto B) {
+        constexpr int b = decltype(B)::value;
+        if constexpr (b % BPW == 0) prep(std::integral_constant<int, b / BPW>{});
+        issue(B);
+        __builtin_amdgcn_sched_barrier(0);
+        piece(B);
+        __builtin_amdgcn_sched_barrier(0);
+        accum(B);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else if constexpr (BITS == 4 && KVQ_K_PIPE) {
       // software pipeline over batches of LKB rotation pairs (2 * LKB look-ups): the look-ups of batch b+1 are on
       // their way while batch b is accumulated -- a wave that has the LDS to itself is no longer a chain of
       // extract -> look-up -> wait -> FMA round trips.  sched_barrier(0) pins the order; the wait counts are hipcc's.
@@ -667,7 +783,9 @@ void score_k_kernel(ScoreKArgs a) {
       static_assert(!SPARSE || PF == 2 || LATE_Q, "the sparse look-ahead registers are a two-set ring");
       // (when there is nothing left to fetch the set is "defined" by an empty asm instead: both paths then
       // define it in place and hipcc needs no merge copy -- which it would place inside the in-flight window)
-      if constexpr (JIT) {
+      if constexpr (WEAVE) {
+        // (the outlier entry was handled between the look-up batches)
+      } else if constexpr (JIT) {
         // entry hh of this lane's token (landed: the wait at the top of this head), then its registers take entry hh+2
         if (hh < nsteps && !(KVQ_ABL & 128)) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);
         sparse_fetch_t(hh + 2 < per_t ? hh + 2 : per_t - 1, spv_all[buf & 1], spc_all[buf & 1]);

@@ -503,6 +503,59 @@ def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows,
     return sink_probs
 
 
+# ---- one decode token through one layer, one library call -----------------------------------------------------------
+def make_layer(kc, vc, table, lut_off):
+    """struct kvq_layer for a (QuantK, QuantV) pair: every pointer of the layer's compressed cache, built once and
+    cached by the caller (the buffers are preallocated and never move).  Returns (struct, keep-alive tuple)."""
+    H, hd, max_len = _cache_dims(kc.kcache, kc.bits)
+    thr_k = kc.num_outliers // 2
+    if _mirror(kc.outliers_t, kc.outlier_indices_t, thr_k, max_len)[0] is None:
+        raise ValueError("decode_step needs the token-contiguous outlier mirror")
+    vn = vc.vnorm_args()
+    vstruct = None
+    if vn is not None:
+        rows2, ns, no, zp2, quirk = vn
+        vstruct = _lib.VNorm(None if rows2 is None else _f(rows2, "lookup_table2"), float(ns), float(no), 1 if zp2 else 0,
+                             1 if quirk else 0)
+    mix = vc.mix_table()
+    ly = _lib.Layer(
+        kc.bits, H, hd, thr_k, max_len, float(kc.rope_theta), int(kc.first_few_fp16),
+        _i(kc.kcache, "kcache"), _f(kc.lookup_table, "lookup_table"), _f(lut_off, "lut_off"),
+        _f(kc.outlier_threshold_lower, "lower"), _f(kc.outlier_threshold_upper, "upper"), _f(kc.outliers, "outliers"),
+        _i(kc.outlier_indices, "outlier_indices"), _f(kc.outliers_t, "outliers_t"), _i(kc.outlier_indices_t, "outlier_indices_t"),
+        None if kc.lut_ends is None else _f(kc.lut_ends, "lut_ends"), None if table is kc.lookup_table else _f(table, "lut_score"),
+        _i(vc.vcache, "vcache"), _f(vc.lookup_table, "lookup_table"), _f(vc.lut, "lut"), _f(vc.outliers, "outliers"),
+        _i(vc.outlier_indices, "outlier_indices"), None if vstruct is None else ctypes.pointer(vstruct),
+        None if mix is vc.lookup_table else _f(mix, "lookup_table2"))
+    return ly, (vstruct, table, lut_off, mix)
+
+
+def decode_step(layer, col, q, k, v, out, fuse_softmax, sinks=None, v_sink=None, sink_probs=None):
+    """kvq_decode_step: prologue + q.K^T + softmax + p.V + reduce of one layer from ONE library call.  layer: struct
+    from make_layer; col: append column (cached tokens before this one, sink tokens not counted); q [H, 128], k, v
+    [C]: all fp16 or all fp32; out f32 [1, H, hd].  sinks = (k_sink, sink_scores (out), inv_sqrt_hd) with v_sink /
+    sink_probs, or None."""
+    kp, kh = _act(k, "k")
+    vp, vh = _act(v, "v")
+    qp, qh = _act(q, "q")
+    if not (kh == vh == qh):
+        raise ValueError("q, k, v must share one dtype (fp32 or fp16)")
+    sk = None
+    if sinks is not None:
+        k_sink, sink_scores, inv = sinks
+        sk = _lib.Sinks(_chk(k_sink, torch.float16, "k_sink"), _chk(sink_scores, torch.float16, "sink_scores"),
+                        sink_scores.shape[1], float(inv))
+    with _Dev(out):
+        nbytes = _L().kvq_decode_step_workspace_bytes(layer.bits, layer.H, layer.hd, int(col) + 1)
+        ws = _workspace(out.device, nbytes + 256, slot="step")
+        base = (ws.data_ptr() + 255) & ~255
+        _lib.check(_L().kvq_decode_step(
+            ctypes.byref(layer), int(col), int(col), qp, kp, vp, kh, None if sk is None else ctypes.byref(sk),
+            None if v_sink is None else _chk(v_sink, torch.float16, "v_sink"),
+            None if sink_probs is None else sink_probs.data_ptr(), _f(out, "out"), 1 if fuse_softmax else 0,
+            base, ws.numel() - (base - ws.data_ptr()), _stream()), "kvq_decode_step")
+
+
 # ---- prefill attention on the matrix cores ----------------------------------------------------------------------
 def prefill_attention(q, k, v, softmax_scale=None):
     """causal attention of a prompt: q, k, v fp16 [H, S, 128] views (any strides with a contiguous last dimension,

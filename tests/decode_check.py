@@ -20,7 +20,7 @@ def quantizer(bits, seed=0, C=C):
     return (upper, lower, [cent]), scale, shift
 
 
-def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=2e-3, norm=False, heads=H):
+def run(device, bits=4, prefill=40, steps=4, max_len=64, tol=1e-3, norm=False, heads=H):
     """prefill `prefill` tokens with parallel_pack, then `steps` decode tokens through decode_kv; returns the
     worst relative error of the attention outputs (asserts the packed state bit for bit).  heads: other model
     widths (hidden = heads * 128; the outlier count follows the reference's int(((1 - t) / 2) * hidden) + 1)."""

