@@ -21,7 +21,7 @@ the 8 KB activation moves between neighbouring ranks point-to-point over RCCL (n
 Per-GPU work is fixed as N grows (32/N layers x N streams x ctx): weak scaling, value = all streams' tokens per
 second.  --streams 1 is the reference's capacity mode (one long-context stream); --replicas keeps the old
 "N independent 32-layer copies" mode.  --shard tokens: ONE stream whose context is split along the token axis (every
-rank streams ctx / N tokens of every layer, one all-gather of [H, hd + 2] floats per layer merges the shards exactly):
+rank streams ctx / N tokens of every layer, one all-gather of [H*hd + 2H] floats per layer merges the shards exactly):
 the placement that speeds a single long stream up; strong scaling.
 """
 import argparse
@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=N_LAYERS)
     ap.add_argument("--sinks", type=int, default=0,
                     help="first_few_fp16 attention-sink tokens kept in fp16 (BASELINE config 3: --bits 3 --sinks 5)")
+    ap.add_argument("--compact", action="store_true",
+                    help="opt-in compact outlier formats (fp16 residual + 16-bit channel: 168 instead of 336 B per token "
+                         "and matvec; NOT the reference's format, reported with its own algorithmic bytes)")
     ap.add_argument("--streams", type=int, default=0, help="decode streams in flight (default: one per rank)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent full copies instead of layer sharding")
     ap.add_argument("--shard", choices=("layers", "tokens"), default="layers",
@@ -61,7 +64,7 @@ def parse():
     ap.add_argument("--retrieval", action="store_true", help="plant a retrievable token and check it (config 5 proxy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp16-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-tokens", type=int, default=16384)
+    ap.add_argument("--cpu-sample-tokens", type=int, default=8192)
     return ap.parse_args()
 
 
@@ -98,14 +101,14 @@ def rope_rotate(x, pos, sign=1.0):
 
 
 class Layer:
-    def __init__(self, bits, max_len, gen, dev, sinks=0):
+    def __init__(self, bits, max_len, gen, dev, sinks=0, compact=False):
         from kvquant_amd.cache import QuantK, QuantV
         quant, self.scale, self.shift = synth_quantizer(bits, gen, dev)
         self.k = QuantK(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
                         include_sparse=True, sparsity_threshold=0.99, rope_theta=THETA, first_few_fp16=sinks,
-                        device=dev)
+                        device=dev, compact=compact)
         self.v = QuantV(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len,
-                        include_sparse=True, sparsity_threshold=0.99, first_few_fp16=sinks, device=dev)
+                        include_sparse=True, sparsity_threshold=0.99, first_few_fp16=sinks, device=dev, compact=compact)
         self.k.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
         self.v.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
         self.sinks = sinks
@@ -227,11 +230,11 @@ class KernelTimers:
         return tot * 1000.0 / len(self.quads)
 
 
-def algorithmic_bytes(bits, L, kernel):
-    """per cached token per layer, formats fixed by the boundary."""
+def algorithmic_bytes(bits, L, kernel, compact=False):
+    """per cached token per layer, formats fixed by the boundary (compact: the opt-in 4-byte entries)."""
     n = 2 ** bits
     dense = C * bits // 8
-    sparse = 42 * 8
+    sparse = 42 * (4 if compact else 8)
     if kernel == "score_k":
         per_tok = dense + sparse + 4 * H                 # + score write
         extra = H * HD * n * 4 + H * HD * 4              # LUT + q
@@ -241,21 +244,66 @@ def algorithmic_bytes(bits, L, kernel):
     return L * per_tok + extra, per_tok
 
 
+def _torch_attention_step(khat, vhat, q):
+    """the reference's CPU formulation of a decode step over reconstructed K / V (what quant/llama_simquant.py's model
+    runs after QuantLinearSim: stock HF attention in fp32): rotary embedding of the cached keys at their positions
+    (rotate_half convention, ML:180-205), q.K^T / sqrt(d), softmax, p.V.  khat / vhat: [L, C] fp32, q: [C]."""
+    L = khat.shape[0]
+    k = khat.view(L, H, HD).transpose(0, 1)                                   # [H, L, hd]
+    v = vhat.view(L, H, HD).transpose(0, 1)
+    inv = 1.0 / (THETA ** (torch.arange(0, HD, 2, dtype=torch.float32) / HD))
+    ang = torch.arange(L, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = torch.cat((ang.cos(), ang.cos()), dim=-1), torch.cat((ang.sin(), ang.sin()), dim=-1)
+    rot = torch.cat((-k[..., HD // 2:], k[..., :HD // 2]), dim=-1)
+    kr = k * cos + rot * sin
+    s = torch.matmul(q.view(H, 1, HD), kr.transpose(1, 2)) / math.sqrt(HD)    # [H, 1, L]
+    p = torch.softmax(s, dim=-1, dtype=torch.float32)
+    return torch.matmul(p, v)                                                 # [H, 1, hd]
+
+
 def cpu_baseline(bits, sample_tokens, ctx, layers):
-    """The reference's CPU path = simulated quantisation (quant/kvquant/simquant_module_quantizer.py:
-    QuantLinearSim fake-quantises the k_proj / v_proj outputs) feeding ordinary fp32 attention.  Two legs on the host
-    cores, bounded samples scaled linearly (~10 s each):
+    """The reference's CPU path = simulated quantisation (quant/kvquant/simquant_module_quantizer.py: QuantLinearSim
+    fake-quantises the k_proj / v_proj outputs) feeding ordinary fp32 attention.  Legs, all on the host cores, bounded
+    samples scaled linearly:
       quantize  -- the reference's own torch formulation (restated in oracle/simquant.py, bit-exact vs the reference
-                   module): per-channel capped-outlier K and per-token dynamic V fake-quant of a block of tokens;
-                   a decode step quantizes ONE new token per layer, a prefill all of them;
-      attention -- fp32 RoPE + q.K^T + softmax + p.V over the reconstructed tokens of one layer (C / OpenMP port)."""
+                   module): per-channel capped-outlier K and per-token dynamic V fake-quant of a block of tokens; a
+                   decode step quantizes ONE new token per layer, a prefill all of them;
+      attention -- the reference's torch-CPU formulation (fp32 RoPE + q.K^T + softmax + p.V over the reconstructed
+                   tokens of one layer, stock-HF arithmetic) at the best of a thread sweep -- `value` is built from this
+                   leg -- and, beside it, the same arithmetic as a C / OpenMP port on all host cores."""
     from oracle import ckernels as ck
     from oracle import simquant as sq
     cores = os.cpu_count() or 1
-    qthreads = min(cores, 16)        # (torch's CPU kernels lose throughput to oversubscription on 100+ core hosts:
-    torch.set_num_threads(qthreads)  #  measured 37 s per 512-token block with 256 threads vs 1 s with 16)
     g = torch.Generator().manual_seed(0)
+    # ---- thread sweep of the torch legs (torch's CPU kernels lose throughput to oversubscription on 100+ core hosts)
+    khat = torch.randn(sample_tokens, C, generator=g)
+    vhat = torch.randn(sample_tokens, C, generator=g)
+    q = torch.randn(C, generator=g)
+    sweep = {}
+    cands = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores})
+    for t in cands:
+        torch.set_num_threads(t)
+        _torch_attention_step(khat[:1024], vhat[:1024], q)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < 1.0:
+            _torch_attention_step(khat, vhat, q)
+            n += 1
+        sweep[t] = (time.time() - t0) / n
+    athreads = min(sweep, key=sweep.get)
+    torch.set_num_threads(athreads)
+    t0 = time.time()
+    reps = 0
+    while True:
+        _torch_attention_step(khat, vhat, q)
+        reps += 1
+        if time.time() - t0 > 6.0 or reps >= 2000:
+            break
+    a_total = time.time() - t0
+    dt_torch = a_total / reps
     # ---- quantize leg
+    qthreads = min(cores, 16)
+    torch.set_num_threads(qthreads)
     n = 2 ** bits
     scale = torch.exp(0.5 * torch.randn(C, generator=g))
     quant = ((2.576 * scale).numpy()[None], (-2.576 * scale).numpy()[None],
@@ -270,7 +318,7 @@ def cpu_baseline(bits, sample_tokens, ctx, layers):
         sq.fake_quant_k(kb, quant, bits, cap_outliers=21)
         sq.fake_quant_v(vb, quant, bits, sparsity_threshold=0.99)
         qreps += 1
-        if time.time() - t0 > 8.0 or qreps >= 200:
+        if time.time() - t0 > 6.0 or qreps >= 200:
             break
     q_total = time.time() - t0
     prefill_tok_s = qreps * blk / q_total / layers           # tokens/s through all layers' K and V
@@ -283,29 +331,31 @@ def cpu_baseline(bits, sample_tokens, ctx, layers):
         if time.time() - t1 > 2.0 or one >= 2000:
             break
     q_one = (time.time() - t1) / one                          # one new token, one layer
-    # ---- attention leg
-    khat = torch.randn(sample_tokens, C, generator=g)
-    vhat = torch.randn(sample_tokens, C, generator=g)
-    q = torch.randn(C, generator=g)
+    # ---- attention leg, C / OpenMP port (all host cores)
     ck.sim_decode_step(khat[:256].contiguous(), vhat[:256].contiguous(), q, H, HD, THETA, 0)  # warm
     t0 = time.time()
-    reps = 0
+    creps = 0
     while True:
         ck.sim_decode_step(khat, vhat, q, H, HD, THETA, 0)
-        reps += 1
-        if time.time() - t0 > 10.0 or reps >= 2000:   # a bounded ~10 s sample of CPU work
+        creps += 1
+        if time.time() - t0 > 5.0 or creps >= 2000:
             break
-    total = time.time() - t0
-    dt = total / reps
-    step_s = (dt * (ctx / sample_tokens) + q_one) * layers
-    return {"value": 1.0 / step_s, "unit": "tokens/s", "cores": ck.num_threads(), "host_cores": cores, "kind": "port",
+    c_total = time.time() - t0
+    dt_c = c_total / creps
+    step_torch = (dt_torch * (ctx / sample_tokens) + q_one) * layers
+    step_c = (dt_c * (ctx / sample_tokens) + q_one) * layers
+    return {"value": 1.0 / step_torch, "unit": "tokens/s", "cores": athreads, "host_cores": cores, "kind": "port",
+            "attention_thread_sweep_s": {str(k): round(v, 4) for k, v in sweep.items()},
+            "c_port": {"value": 1.0 / step_c, "cores": ck.num_threads(), "seconds_per_sample": dt_c},
             "prefill_quantize_tokens_per_s": prefill_tok_s,
-            "sample": "attention: %d x (1 layer x %d reconstructed tokens: fp32 RoPE+qK^T+softmax+pV, oracle C/OpenMP, %d "
-                      "threads) = %.1f s, %.3f s each, scaled x%g tokens x%d layers; quantize: %d x (%d-token block, "
-                      "per-channel capped K + per-token dynamic V fake-quant, torch CPU on %d threads = the reference's formulation) = "
-                      "%.1f s -> %.0f prompt tokens/s through %d layers; one new token per layer per decode step = %.2f ms"
-                      % (reps, sample_tokens, ck.num_threads(), total, dt, ctx / sample_tokens, layers, qreps, blk,
-                         qthreads, q_total, prefill_tok_s, layers, q_one * 1e3)}
+            "sample": "attention (value): %d x (1 layer x %d reconstructed tokens: fp32 RoPE + q.K^T + softmax + p.V in the "
+                      "reference's torch-CPU formulation on %d threads, the best of the sweep %s over %d host cores) = %.1f s, "
+                      "%.3f s each, scaled x%g tokens x%d layers; the same arithmetic as a C / OpenMP port on %d threads: %.3f s "
+                      "each; quantize: %d x (%d-token block, per-channel capped K + per-token dynamic V fake-quant, torch CPU on "
+                      "%d threads = the reference's formulation) = %.1f s -> %.0f prompt tokens/s through %d layers; one new "
+                      "token per layer per decode step = %.2f ms"
+                      % (reps, sample_tokens, athreads, cands, cores, a_total, dt_torch, ctx / sample_tokens, layers,
+                         ck.num_threads(), dt_c, qreps, blk, qthreads, q_total, prefill_tok_s, layers, q_one * 1e3)}
 
 
 def fp16_matvec_baseline(ctx, dev, iters=10):
@@ -394,13 +444,16 @@ def run_token_sharded(args, rank, world, dev, dist):
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
+    from kvquant_amd.cache import shard_record_floats
+    record = torch.empty(shard_record_floats(H, HD), dtype=torch.float32, device=dev)
+
     def step(st):
         out = None
         for lay, q, k, v in layers:
             qq = q[st] if out is None else q[st] + out.view(H, HD).half() * 1e-3      # (a true dependency on the merge)
-            fn = (lambda: shard_attention(lay.k, lay.v, qq, k[st], v[st], pos_base=lo)) if last else \
-                (lambda: shard_attention(lay.k, lay.v, qq, pos_base=lo))
-            out = sharding.token_sharded_step(fn)
+            fn = (lambda rec: shard_attention(lay.k, lay.v, qq, k[st], v[st], pos_base=lo, record=rec)) if last else \
+                (lambda rec: shard_attention(lay.k, lay.v, qq, pos_base=lo, record=rec))
+            out = sharding.token_sharded_step(fn, record)
         return out
 
     for st in range(args.warmup):
@@ -457,7 +510,7 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
     plant_q = None
     for s in range(streams):
         for li in owned:
-            lay = Layer(args.bits, max_len, gen, dev, args.sinks)
+            lay = Layer(args.bits, max_len, gen, dev, args.sinks, getattr(args, "compact", False))
             plant = None
             if args.retrieval and li == owned[0] and s == 0:
                 # query 3x the usual norm at the decode position; the planted key is the query rotated back to its
@@ -520,10 +573,10 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
         k_us, v_us = timers.mean_us("score_k"), timers.mean_us("mix_v")
         dom = "score_k" if (k_us or 0) >= (v_us or 0) else "mix_v"
         dom_us = k_us if dom == "score_k" else v_us
-        dom_bytes, per_tok = algorithmic_bytes(args.bits, L_mid, dom)
+        dom_bytes, per_tok = algorithmic_bytes(args.bits, L_mid, dom, getattr(args, "compact", False))
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        kb, _ = algorithmic_bytes(args.bits, L_mid, "score_k")
-        vb, _ = algorithmic_bytes(args.bits, L_mid, "mix_v")
+        kb, _ = algorithmic_bytes(args.bits, L_mid, "score_k", getattr(args, "compact", False))
+        vb, _ = algorithmic_bytes(args.bits, L_mid, "mix_v", getattr(args, "compact", False))
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
         if os.path.exists(tpath):
@@ -532,6 +585,8 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
                 traffic = tj.get(dom, {}).get("%d_%d" % (args.bits, args.ctx), tj.get(dom, {}).get(str(args.ctx)))
                 if args.bits != 4 and ("%d_%d" % (args.bits, args.ctx)) not in tj.get(dom, {}):
                     traffic = None
+                if getattr(args, "compact", False):
+                    traffic = None          # (the kept PMC bytes are those of the reference format)
                 traffic_src = tj.get("_source")
             except Exception:
                 traffic = None
@@ -553,7 +608,9 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
                                    % (args.layers, args.bits, args.ctx,
                                       " + %d fp16 attention-sink tokens" % args.sinks if args.sinks else ""),
                        "ctx": args.ctx, "bits": args.bits, "layers": args.layers, "sinks": args.sinks,
-                       "streams": streams, "parallelism": par},
+                       "streams": streams, "parallelism": par,
+                       "outlier_format": "compact (fp16 residual + u16 channel, opt-in)" if getattr(args, "compact", False)
+                       else "reference (f32 + i32)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
@@ -624,17 +681,19 @@ def main():
             raise SystemExit("--sweep is a single-GPU run")
         base = dict(vars(args))
         # (label, ctx, bits, sinks, layers, steps): BASELINE configs 2, 3, 5 and the north-star sizes
-        cfgs = [("4K hot (1 layer, Infinity-Cache resident)", 4096, 4, 0, 1, 50),
-                ("4K rotated (32 layers)", 4096, 4, 0, 32, 20),
-                ("32K", 32768, 4, 0, 32, 20),
-                ("128K nuq3 + 5 sinks (config 3)", 131072, 3, 5, 32, 10),
-                ("32K nuq3 + 5 sinks", 32768, 3, 5, 32, 20),
-                ("1M (config 5 shape on one GPU: 8 of 32 layers, retrieval proxy)", 1048576, 4, 0, 8, 5),
-                ("1M nuq3 + 5 sinks (8 of 32 layers)", 1048576, 3, 5, 8, 5)]
-        for label, ctx, bits, sinks, layers, steps in cfgs:
+        cfgs = [("4K hot (1 layer, Infinity-Cache resident)", 4096, 4, 0, 1, 50, False),
+                ("4K rotated (32 layers)", 4096, 4, 0, 32, 20, False),
+                ("32K", 32768, 4, 0, 32, 20, False),
+                ("128K nuq3 + 5 sinks (config 3)", 131072, 3, 5, 32, 10, False),
+                ("32K nuq3 + 5 sinks", 32768, 3, 5, 32, 20, False),
+                ("128K, compact outlier format (opt-in)", 131072, 4, 0, 32, 10, True),
+                ("128K nuq3 + 5 sinks, compact outlier format (opt-in)", 131072, 3, 5, 32, 10, True),
+                ("1M (config 5 shape on one GPU: 8 of 32 layers, retrieval proxy)", 1048576, 4, 0, 8, 5, False),
+                ("1M nuq3 + 5 sinks (8 of 32 layers)", 1048576, 3, 5, 8, 5, False)]
+        for label, ctx, bits, sinks, layers, steps, compact in cfgs:
             a = argparse.Namespace(**base)
-            a.ctx, a.bits, a.sinks, a.layers, a.steps = ctx, bits, sinks, layers, steps
-            a.retrieval = ctx >= 1048576
+            a.ctx, a.bits, a.sinks, a.layers, a.steps, a.compact = ctx, bits, sinks, layers, steps, compact
+            a.retrieval = ctx >= 1048576 and not compact
             r = run_config(a, rank, world, dev, dist, label=label, with_baselines=False)
             print(json.dumps(r), flush=True)
     if args.shard == "tokens":

@@ -354,6 +354,21 @@ KVQ_API int kvq_decode_steps(int n_layers, const kvq_layer *layers, int64_t col,
                      const void *const *k, const void *const *v, int acts_are_half, float *const *out,
                      int fuse_softmax, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- one decode stream over a context split along the token axis (one shard per GPU) ---- */
+
+/* The query-premultiplied K codebook images of kvq_score_k_prepared[_softmax] into `workspace`
+ * (kvq_score_k_workspace_bytes(bits, 1, H)) without an append: the shards that do not hold the newest token only score.
+ * q: [H][128] RoPE'd query, fp32 or fp16; lut: the table the scores dequantise with. */
+KVQ_API int kvq_score_k_tables(int bits, const void *q, int q_is_half, const float *lut, int H, int hd,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* stats[h] = (max, sum of exp(x - max)) of head h's scaled scores over the shard, merged from the partials that
+ * kvq_score_k_prepared_softmax wrote (the per-row part of kvq_softmax_finish); float [H][2]. */
+KVQ_API int kvq_softmax_stats(const float *parts, int n_parts, int H, float *stats, void *stream);
+/* Exact merge of n_shards locally normalised attention outputs (flash-decoding across devices): packed = n_shards
+ * records of [H*hd floats: the shard's output][H x (max, normaliser): kvq_softmax_stats], e.g. the result of ONE
+ * all-gather per layer; a shard without tokens carries (-inf, 0).  out: float [H][hd]. */
+KVQ_API int kvq_combine_shards(const float *packed, int n_shards, int H, int hd, float *out, void *stream);
+
 /* ---- prefill attention (the MFMA path of BASELINE config 4) ----------------------- */
 
 /* Causal self-attention of the S prompt tokens of one sequence, all heads, flash-style on the gfx950 matrix cores

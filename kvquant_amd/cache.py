@@ -55,10 +55,12 @@ class QuantK(nn.Module):
 
     def __init__(self, bits=2, hidden_size=4096, num_heads=32, max_position_embeddings=-1,
                  include_sparse=False, sparsity_threshold=0.99, rope_theta=10000, use_orig_sparse=False,
-                 first_few_fp16=0, device=None):
+                 first_few_fp16=0, device=None, compact=False):
         super().__init__()
         if bits not in (2, 3, 4):
             raise ValueError("bits must be 2, 3 or 4")
+        if compact and not include_sparse:
+            raise ValueError("compact is a format of the Dense-and-Sparse cache (include_sparse)")
         if use_orig_sparse and bits != 4:
             raise ValueError("use_orig_sparse is 4-bit only (as the reference, ML:513)")
         self.hidden_size = hidden_size
@@ -79,7 +81,16 @@ class QuantK(nn.Module):
                                   device=dev)
         # the reference hard-codes 42 columns (ML:396); same value at 0.99 / 4096
         self.num_outliers = 2 * _threshold_k(sparsity_threshold, hidden_size)
-        if include_sparse:
+        # compact=True (opt-in, NOT the reference's format): the outliers of a token are kept ONLY as packed
+        # entries fp16 residual << 16 | channel in the token-contiguous mirror -- 168 B per token instead of 336 (+336
+        # for the reference-layout rows, which are not kept).  The residual is rounded to fp16 (relative 2^-11 of an
+        # outlier's residual); everything else is bit-identical.  Only the GPU-resident decode path (decode_kv,
+        # parallel_pack) reads this format.
+        self.compact = bool(compact)
+        if include_sparse and self.compact:
+            self.outliers = self.outlier_indices = self.outliers_t = None
+            self.outlier_indices_t = torch.zeros((self.num_outliers, self.max_len), dtype=torch.int32, device=dev)
+        elif include_sparse:
             self.outliers = torch.zeros((self.max_len, self.num_outliers), dtype=torch.float32, device=dev)
             self.outlier_indices = torch.zeros((self.max_len, self.num_outliers), dtype=torch.int32, device=dev)
             # token-contiguous mirror of the two buffers above ([slot][token]); kept in step by every append
@@ -113,10 +124,9 @@ class QuantK(nn.Module):
         self.klen = 0
         self.kcache.zero_()
         if self.include_sparse:
-            self.outliers.zero_()
-            self.outlier_indices.zero_()
-            self.outliers_t.zero_()
-            self.outlier_indices_t.zero_()
+            for t in (self.outliers, self.outlier_indices, self.outliers_t, self.outlier_indices_t):
+                if t is not None:
+                    t.zero_()
             self._reset_csr(self.device)
 
     def load_lookup_table(self, quantizer, include_sparse=True, sparsity_threshold=0.99, norm=False):
@@ -178,6 +188,8 @@ class QuantK(nn.Module):
         """The GPU-resident core of forward_fused_sparse: q f32 [q_len, H, hd] (post-RoPE),
         k f32 [C] (pre-RoPE).  Appends k (pack + outlier row, one launch) and returns the raw
         scores f32 [q_len, H, L] (one launch).  No host synchronisation."""
+        if self.compact:
+            raise NotImplementedError("compact caches are read by decode_kv only (the reference-format kernels need the rows)")
         pos = self.klen - self.first_few_fp16
         if self.include_sparse:
             lut_off = self.lookup_table2 if self.norm else self.lookup_table
@@ -216,6 +228,8 @@ class QuantK(nn.Module):
         k = k.float().contiguous()
         S = k.shape[-1]
         col0 = _pack_col0(self.klen, self.first_few_fp16)
+        if self.compact and not fused:
+            raise NotImplementedError("compact caches take the fused prefill pack only")
         if fused:
             # one launch: pack + exact top-k selection + outlier rows (+ mirror), one workgroup per token
             lut_off = self.lookup_table2 if self.norm else self.lookup_table
@@ -297,10 +311,13 @@ class QuantV(nn.Module):
     """Compressed value cache with per-token codebooks (ML:978-1385)."""
 
     def __init__(self, bits=2, hidden_size=4096, num_heads=32, max_position_embeddings=-1,
-                 include_sparse=False, sparsity_threshold=0.99, first_few_fp16=0, device=None):
+                 include_sparse=False, sparsity_threshold=0.99, first_few_fp16=0, device=None, compact=False):
         super().__init__()
         if bits not in (2, 3, 4):
             raise ValueError("bits must be 2, 3 or 4")
+        if compact and not include_sparse:
+            raise ValueError("compact is a format of the Dense-and-Sparse cache (include_sparse)")
+        self.compact = bool(compact)
         self.hidden_size = hidden_size
         self.num_heads = num_heads
         self.head_dim = hidden_size // num_heads
@@ -316,7 +333,12 @@ class QuantV(nn.Module):
                                   device=dev)
         self.vlen = 0
         self.num_outliers = 2 * _threshold_k(sparsity_threshold, hidden_size)
-        if include_sparse:
+        if include_sparse and self.compact:
+            # compact=True (opt-in, see QuantK): rows of packed entries fp16 residual << 16 | channel in outlier_indices,
+            # no value array: 168 B per token instead of 336
+            self.outliers = None
+            self.outlier_indices = torch.zeros((self.max_len, self.num_outliers), dtype=torch.int32, device=dev)
+        elif include_sparse:
             self.outliers = torch.zeros((self.max_len, self.num_outliers), dtype=torch.float32, device=dev)
             self.outlier_indices = torch.zeros((self.max_len, self.num_outliers), dtype=torch.int32, device=dev)
         self.first_few_fp16 = first_few_fp16
@@ -341,7 +363,8 @@ class QuantV(nn.Module):
         self.lookup_table.zero_()
         self.vcache.zero_()
         if self.include_sparse:
-            self.outliers.zero_()
+            if self.outliers is not None:
+                self.outliers.zero_()
             self.outlier_indices.zero_()
         if self.lookup_table2 is not None:
             self.lookup_table2.zero_()
@@ -411,6 +434,8 @@ class QuantV(nn.Module):
         (C values).  With include_sparse the four top-(thr+1) tensors may be passed as
         in the reference (they are then used as given) or left None: selection then
         happens inside the fused GPU append."""
+        if self.compact:
+            raise NotImplementedError("compact caches are read by decode_kv only")
         score = score.float()
         v_in = v.flatten()
         v = v_in.float().contiguous()
@@ -480,6 +505,8 @@ class QuantV(nn.Module):
         v = v.float().contiguous()
         S = v.shape[-1]
         col0 = _pack_col0(self.vlen, self.first_few_fp16)
+        if self.compact and upper_outlier_vals is not None:
+            raise NotImplementedError("compact caches take the fused prefill pack only")
         if upper_outlier_vals is None:
             # one launch: top-(k+1) selection, per-token codebook rows, pack, outlier rows
             ops.pack_v_fused(self.bits, self.vcache, self.lookup_table, self.lut, v, self.outliers,
@@ -552,10 +579,13 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         sink_scores = torch.empty((kc.num_heads, k_sink.shape[2]), dtype=torch.float16, device=kc.device)
         sinks = (k_sink, sink_scores, inv)
     H = kc.num_heads
-    if ONE_CALL_PER_LAYER and kpos == vpos and (sink_scores is None or sinks is not None):
+    compact = getattr(kc, "compact", False) or getattr(vc, "compact", False)
+    if compact and not (kpos == vpos and (sink_scores is None or sinks is not None)):
+        raise ValueError("compact caches: decode_kv with k_sink / v_sink (or no sinks), K and V in step")
+    if (ONE_CALL_PER_LAYER or compact) and kpos == vpos and (sink_scores is None or sinks is not None):
         # the whole launch sequence from one library call (kvq_decode_step): the five Python / ctypes round trips of
         # the path below cost ~78 us of host time per layer, as much as the GPU needs for a 4K-token cache
-        key = (id(vc), getattr(vc, "_tables_version", 0), vc.reference_tie_quirk, vc.norm, kc.norm)
+        key = (id(vc), getattr(vc, "_tables_version", 0), vc.reference_tie_quirk, vc.norm, kc.norm, kc.compact, vc.compact)
         cached = getattr(kc, "_step_layer", None)
         if cached is None or cached[0] != key:
             cached = (key,) + ops.make_layer(kc, vc, table, lut_off)
@@ -592,24 +622,44 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
     return out, sink_probs
 
 
-def shard_attention(kc, vc, q, k=None, v=None, pos_base=0):
+def shard_record_floats(H, hd):
+    """floats of one shard's record: [H*hd: output normalised over the shard][H x (max, normaliser)]"""
+    return H * hd + 2 * H
+
+
+def shard_attention(kc, vc, q, k=None, v=None, pos_base=0, record=None):
     """Attention of one decode token over ONE SHARD of a context that is split along the token axis (SURVEY 8e asks
     for layer / head placement; this is the third cut, the one that speeds up a single long stream: every GPU holds
     L / N cached tokens of every layer and streams only those).  kc / vc hold the shard's tokens, whose positions
     start at `pos_base`; k, v (the new token) are appended to THIS shard when given -- the owner of the newest tokens
-    -- and the other shards only score.  Returns (out f32 [1, H, hd] normalised over the shard, M f32 [H], Z f32 [H]):
-    the shard's softmax maximum and normaliser of the scaled fp16 scores, from the score kernel's partials, so that
-    `combine_shards` can merge the shards exactly (flash-decoding across devices; the probabilities are rounded to
-    fp16 per shard instead of over the whole row, a last-bit effect).  Sparse caches with the outlier mirror."""
+    -- and the other shards only score.  Everything stays in library launches (no torch arithmetic): table prep or
+    prologue -> q.K^T + softmax partials -> softmax finish -> softmax statistics -> p.V -> slab reduce.
+    Returns (out f32 [1, H, hd] normalised over the shard, M f32 [H], Z f32 [H]) -- views of `record` (f32
+    [shard_record_floats], allocated when None), the buffer that goes into the all-gather: the shard's softmax maximum
+    and normaliser of the scaled fp16 scores, so that the shards merge exactly (flash-decoding across devices; the
+    probabilities are rounded to fp16 per shard instead of over the whole row, a last-bit effect).  An EMPTY shard
+    (no cached tokens, no new one) returns zeros with (M, Z) = (-inf, 0).  Sparse caches with the outlier mirror;
+    fp16 sink tokens are not supported here (they would belong to the first shard only)."""
     if not (kc.include_sparse and vc.include_sparse):
         raise ValueError("shard_attention needs include_sparse caches")
-    bits, H = kc.bits, kc.num_heads
+    if kc.first_few_fp16 > 0:
+        raise ValueError("shard_attention: fp16 attention-sink tokens are not supported on a sharded context")
+    bits, H, hd = kc.bits, kc.num_heads, vc.head_dim
+    if record is None:
+        record = torch.empty(shard_record_floats(H, hd), dtype=torch.float32, device=kc.device)
+    out = record[:H * hd].view(1, H, hd)
+    stats = record[H * hd:].view(H, 2)
     inv = 1.0 / (kc.head_dim ** 0.5)
     table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
-    pos_offset = kc.first_few_fp16 + int(pos_base)
+    pos_offset = int(pos_base)
+    if k is None and kc.klen == 0:
+        out.zero_()
+        stats[:, 0] = float("-inf")
+        stats[:, 1] = 0.0
+        return out, stats[:, 0], stats[:, 1]
     if k is not None:
-        kpos = kc.klen - kc.first_few_fp16
-        vpos = vc.vlen - vc.first_few_fp16
+        kpos = kc.klen
+        vpos = vc.vlen
         lut_off = kc.lookup_table2 if kc.norm else kc.lookup_table
         ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
                                  kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
@@ -619,38 +669,28 @@ def shard_attention(kc, vc, q, k=None, v=None, pos_base=0):
         kc.klen += 1
         vc.vlen += 1
     else:
-        # tables of q into the score workspace (the score entry point builds them before its kernel)
-        dummy = torch.zeros((1, H, 1), dtype=torch.float32, device=kc.device)
-        ops.score_k(bits, q.float().unsqueeze(0).contiguous(), kc.kcache, dummy, table, 1, kc.rope_theta, 0,
-                    accumulate=False)
-        ws = ops._workspace(kc.device, ops._L().kvq_score_k_workspace_bytes(bits, 1, H), slot="score")
-    L = kc.klen - kc.first_few_fp16
+        ws = ops.score_k_tables(bits, q, table, H)
+    L = kc.klen
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
-    out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
     n_parts = ops._L().kvq_score_k_softmax_parts(bits, L, 1)
-    if n_parts > 0:
-        parts = ops.score_k_prepared_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, pos_offset, ws,
-                                             kc.outliers, kc.outlier_indices, inv, n_parts, kc.outliers_t,
-                                             kc.outlier_indices_t)
-        pm = parts[:H * n_parts * 8].view(torch.float32).view(H, n_parts, 2)
-        M = pm[..., 0].max(dim=-1).values
-        Z = (pm[..., 1] * torch.exp(pm[..., 0] - M[:, None])).sum(dim=-1)
-        probs, _ = ops.softmax_finish(scores[0], parts, n_parts, inv)
-    else:
-        ops.score_k_prepared(bits, kc.kcache, scores, table, L, kc.rope_theta, pos_offset, ws, kc.outliers,
-                             kc.outlier_indices)
-        sc = (scores[0].half() * inv).float()       # half(half(s) * inv), as the kernels scale
-        M = sc.max(dim=-1).values
-        Z = torch.exp(sc - M[:, None]).sum(dim=-1)
-        probs, _ = ops.softmax_scale(scores[0], inv)
+    if n_parts <= 0:
+        raise ValueError("shard_attention: unsupported shape")
+    parts = ops.score_k_prepared_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, pos_offset, ws,
+                                         kc.outliers, kc.outlier_indices, inv, n_parts, kc.outliers_t,
+                                         kc.outlier_indices_t)
+    ops.softmax_stats(parts, n_parts, H, stats)
+    probs, _ = ops.softmax_finish(scores[0], parts, n_parts, inv)
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
               accumulate=False)
-    return out, M, Z
+    return out, stats[:, 0], stats[:, 1]
 
 
 def combine_shards(outs, Ms, Zs):
     """exact merge of per-shard attention: out = sum_r w_r out_r / sum_r w_r with w_r = Z_r exp(M_r - max_r M_r).
-    outs [R, 1, H, hd], Ms / Zs [R, H] (stacked over the shards, any device)."""
+    outs [R, 1, H, hd], Ms / Zs [R, H] (stacked over the shards, any device); shards without tokens carry (-inf, 0).
+    Plain torch (CPU tests, reference for kvq_combine_shards -- the GPU path merges the gathered records with that
+    kernel, see sharding.token_sharded_step)."""
     Mg = Ms.max(dim=0).values
-    w = Zs * torch.exp(Ms - Mg[None, :])                   # [R, H]
-    return (outs * w[:, None, :, None]).sum(dim=0) / w.sum(dim=0)[None, :, None]
+    w = torch.where(torch.isfinite(Ms), Zs * torch.exp(Ms - Mg[None, :]), torch.zeros_like(Zs))      # [R, H]
+    den = w.sum(dim=0)
+    return (outs * w[:, None, :, None]).sum(dim=0) / torch.where(den > 0, den, torch.ones_like(den))[None, :, None]

@@ -66,7 +66,9 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
                     int acts_are_half, const kvq_sinks *sinks, const uint16_t *v_sink, uint16_t *sink_probs,
                     float *out, int fuse_softmax, void *workspace, size_t workspace_bytes, void *stream) {
   if (!ly || !q || !k || !v || !out || kcol < 0 || vcol != kcol) return KVQ_EINVAL;
-  if (!ly->koutliers || !ly->voutliers || !ly->koutliers_t || !ly->kidx_t) return KVQ_EINVAL;   // Dense-and-Sparse caches with the mirror
+  // Dense-and-Sparse caches with the K mirror; value arrays may be absent (COMPACT formats: packed entries in the index
+  // arrays, include/kvq.h)
+  if (!ly->kidx_t || !ly->vidx || (ly->koutliers && !ly->kidx) || (ly->koutliers_t && !ly->kidx_t)) return KVQ_EINVAL;
   if (v_sink && (!sinks || !sink_probs)) return KVQ_EINVAL;
   const int bits = ly->bits, H = ly->H, hd = ly->hd;
   const int64_t L = kcol + 1;                       // cached tokens after the append (sink tokens not counted)

@@ -26,6 +26,14 @@ constexpr int kSelThreads = 1024;
 constexpr int kSelWaves = kSelThreads / 64;
 constexpr int kMaxPerLane = 8;  // channels per lane: C <= 8192
 
+// COMPACT outlier entry (opt-in format): fp16 residual in the high half, channel (< 65536) in the low half --
+// 4 bytes instead of the reference's f32 value + i32 index.  Convention of every entry point that takes an
+// (outliers, outlier_idx) or a mirror pair: a NULL value pointer with a non-NULL index pointer means "packed entries in
+// the index array".
+__device__ __forceinline__ int32_t pack_entry(float val, int c) {
+  return (int32_t)(((uint32_t)__half_as_ushort(__float2half_rn(val)) << 16) | (uint32_t)c);
+}
+
 __device__ __forceinline__ uint32_t fkey(float x) {  // ascending order-preserving
   uint32_t b = __float_as_uint(x);
   return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
@@ -388,12 +396,18 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
       else val = (sel[e] >= -1.0f) ? 0.f : xv[e] - (have_ends ? end_lo[e] : lut_off[(int64_t)c * N]);
     }
     if ((int)pos < n_out) {
-      orow[pos] = val;
-      irow[pos] = c0 + e;
+      if (outliers != nullptr) {
+        orow[pos] = val;
+        irow[pos] = c0 + e;
+      } else if (outlier_idx != nullptr) {
+        irow[pos] = pack_entry(val, c0 + e);                  // compact rows
+      }
       if constexpr (!IS_V) {
         if (A.outliers_t != nullptr) {
           A.outliers_t[(int64_t)pos * max_len + col] = val;
           A.outlier_idx_t[(int64_t)pos * max_len + col] = c0 + e;
+        } else if (A.outlier_idx_t != nullptr) {
+          A.outlier_idx_t[(int64_t)pos * max_len + col] = pack_entry(val, c0 + e);   // compact mirror
         }
       }
     }
@@ -520,12 +534,14 @@ __global__ __launch_bounds__(kSelThreads) void decode_prologue_kernel(PrologueAr
 }
 
 static int check_append(bool is_v, const AppendArgs &a, int H, int hd) {
-  if (!a.mat || !a.x || !a.outliers || !a.outlier_idx || a.thr_k <= 0 || H <= 0 || hd <= 0 || hd % 32 ||
+  // outlier destinations: rows (f32 + i32, or index array alone = packed entries) and / or, K, the mirror
+  if ((a.outliers && !a.outlier_idx) || (!a.outlier_idx && (is_v || !a.outlier_idx_t))) return KVQ_EINVAL;
+  if (!a.mat || !a.x || a.thr_k <= 0 || H <= 0 || hd <= 0 || hd % 32 ||
       a.col < 0 || a.col >= a.max_len || a.C > kMaxPerLane * kSelThreads || 2 * (a.thr_k + 1) > a.C ||
       a.C >= 65536)
     return KVQ_EINVAL;
   if (is_v ? (!a.lut_rows || !a.lut_sorted) : (!a.lut || !a.lut_off || !a.lo || !a.hi)) return KVQ_EINVAL;
-  if ((a.outliers_t == nullptr) != (a.outlier_idx_t == nullptr)) return KVQ_EINVAL;
+  if (a.outliers_t != nullptr && a.outlier_idx_t == nullptr) return KVQ_EINVAL;   // (index alone: the compact mirror)
   return KVQ_OK;
 }
 

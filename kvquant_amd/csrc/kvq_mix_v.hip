@@ -463,7 +463,9 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 
   const uint32_t lds0 = lds_addr(smem);
   const DmaLane dl = make_dma_lane<BITS>();
-  const bool sparse = (a.outliers != nullptr) && (b == 0);   // reference: batch 0 only (KCU:3675)
+  const bool sparse = (a.idx != nullptr) && (b == 0);        // reference: batch 0 only (KCU:3675)
+  // COMPACT rows (opt-in format): no value array, `idx` holds packed entries fp16 residual << 16 | channel
+  const bool compact = a.outliers == nullptr;
   // The sparse phase is bound by memory latency (VALU and LDS idle), the dense loop by the LDS pipe.  Half of the
   // workgroups run it BEFORE their dense loop, the other half after it: wherever two workgroups share a CU in either
   // order, one's latency-bound phase hides behind the other's look-ups (all of them at the end: 19 % of the kernel
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     const int64_t s1 = (s0 + share < t1) ? (s0 + share) : t1;
     const int ns = s1 > s0 ? (int)(s1 - s0) : 0;             // tokens of the share
     const unsigned nent = (unsigned)ns * (unsigned)a.n_out;  // < 2^31
-    const float *ov = a.outliers + s0 * a.n_out;
+    const float *ov = compact ? reinterpret_cast<const float *>(a.idx + s0 * a.n_out) : a.outliers + s0 * a.n_out;
     const int32_t *oi = a.idx + s0 * a.n_out;
     const float *p0 = (FUSED ? a.scores : a.p) + s0;   // FUSED: raw scores, converted on the way
     float *sslab = a.sparse_partial + (int64_t)blockIdx.x * C;
@@ -595,8 +597,12 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       for (int j = 0; j < RB; j++) {
         const unsigned e = base + j * Cfg::NT + tid;
         const unsigned ec = e < nent ? e : (nent ? nent - 1 : 0);
-        row[j] = oi[ec];
-        val[j] = ov[ec];
+        // (branch-free on purpose: a branch in here makes hipcc lose the wave-uniformity of the DMA bases further down.
+        //  Compact rows: `ov` aliases the packed array, the second load hits the line the first one fetched.)
+        const uint32_t w = (uint32_t)oi[ec];
+        const float fv = ov[ec];
+        row[j] = compact ? (int)(w & 0xffffu) : (int)w;
+        val[j] = compact ? __half2float(__ushort_as_half((unsigned short)(w >> 16))) : fv;
       }
     };
 #if KVQ_TRACE
@@ -1255,7 +1261,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   const int C = a.H * kHeadDim;
   dim3 rgrid((C + 15) / 16, a.q_len);
   mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, a.sparse_partial, mul, pl.n_ranges,
-                                             a.outliers ? pl.n_ranges * pl.groups : 0, a.q_len, C, accumulate);
+                                             a.idx ? pl.n_ranges * pl.groups : 0, a.q_len, C, accumulate);
   return check_launch();
 }
 
@@ -1289,8 +1295,8 @@ static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int
   if (!p || !mat || !mul || !lut_rows || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 || L > max_len ||
       bits < 2 || bits > 4)
     return KVQ_EINVAL;
-  const bool sparse = outliers != nullptr;
-  if (sparse && (!outlier_idx || n_out <= 0)) return KVQ_EINVAL;
+  const bool sparse = outlier_idx != nullptr;     // (without `outliers`: compact rows, packed entries in outlier_idx)
+  if ((outliers && !outlier_idx) || (sparse && n_out <= 0)) return KVQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (L == 0) {
     if (!accumulate) {
@@ -1301,7 +1307,7 @@ static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int
   if (!workspace || workspace_bytes < ws_bytes(bits, q_len, H, L)) return KVQ_EWORKSPACE;
   const bool fast = mix_fast_shape(mat, lut_rows, H, hd, L, max_len, bits);
   if (!fast) {
-    if (fs) return KVQ_EINVAL;
+    if (fs || (sparse && !outliers)) return KVQ_EINVAL;      // (the row-per-lane fallback reads the reference format only)
     MixPlan pl = plan_mix_rows(bits, q_len, H, L, sparse);
     MixVArgs a;
     a.p = p;

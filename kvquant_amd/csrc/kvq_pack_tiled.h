@@ -280,12 +280,18 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
       else val = (sel[e] >= -1.0f) ? 0.f : xs_[(int64_t)c * S] - A.lut_off[(int64_t)c * N];
     }
     if ((int)pos < n_out) {
-      orow[pos] = val;
-      irow[pos] = c;
+      if (A.outliers != nullptr) {
+        orow[pos] = val;
+        irow[pos] = c;
+      } else if (A.outlier_idx != nullptr) {
+        irow[pos] = pack_entry(val, c);                       // compact rows
+      }
       if constexpr (!IS_V) {
         if (A.outliers_t != nullptr) {
           A.outliers_t[(int64_t)pos * max_len + col] = val;
           A.outlier_idx_t[(int64_t)pos * max_len + col] = c;
+        } else if (A.outlier_idx_t != nullptr) {
+          A.outlier_idx_t[(int64_t)pos * max_len + col] = pack_entry(val, c);   // compact mirror
         }
       }
     }

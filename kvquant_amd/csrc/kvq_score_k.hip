@@ -149,10 +149,13 @@ constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse varian
 // SPARSE: fused outlier SpMV.  TRANSPOSED (implies SPARSE): the outliers come from the token-contiguous
 // mirror [n_out][max_len] that kvquant_amd's own cache keeps next to the reference's [max_len][n_out]
 // rows: a lane then owns ITS token's entries (coalesced loads, no segmented scan, no index division).
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false>
+// COMPACT (implies TRANSPOSED): the mirror holds packed entries -- fp16 residual << 16 | channel, 4 bytes instead of 8 --
+// in idx_t (opt-in format of kvquant_amd's own cache); one load per entry.
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false>
 __global__ __launch_bounds__(NWAVES * 64, 4) 
 void score_k_kernel(ScoreKArgs a) {
   static_assert(!TRANSPOSED || SPARSE, "the transposed mirror is a sparse variant");
+  static_assert(!COMPACT || TRANSPOSED, "packed entries live in the mirror");
   constexpr int N = Fmt<BITS>::kN;
   constexpr int WPH = Fmt<BITS>::kWordsPerHead;
   constexpr int T = NWAVES * 32;
@@ -180,7 +183,7 @@ void score_k_kernel(ScoreKArgs a) {
   constexpr bool JIT = KVQ_K_JIT && TRANSPOSED && !KVQ_K_SPARSE_AFTER && PF == 2;
   constexpr bool WEAVE = KVQ_K_WEAVE && JIT && BITS == 4;
   // (WEAVE: the table pieces are issued behind the first two word re-loads of the head)
-  constexpr int JIT_OPS = 2 * BITS + 2 - (WEAVE ? 2 : 0);
+  constexpr int JIT_OPS = 2 * BITS + (COMPACT ? 1 : 2) - (WEAVE ? 2 : 0);
   // VMEM operations of one look-ahead step that EVERY wave issues (waves with an extra table piece wait
   // for one more than they need to)
   constexpr int STEP_OPS = 2 * BITS + TAB_DMA / NWAVES;
@@ -253,7 +256,7 @@ void score_k_kernel(ScoreKArgs a) {
   // of 32*n_out entries, walked in 64-lane chunks (fully coalesced, all lanes busy), ONE CHUNK PER HEAD
   // ITERATION of the dense loop, fetched one iteration ahead: the sparse work hides in the dense loop's
   // memory waits instead of being a serial, latency-bound prologue in every workgroup at once.
-  const bool do_sparse = SPARSE && b == 0 && (TRANSPOSED ? a.out_t != nullptr : a.outliers != nullptr);   // reference: batch 0 only (KCU:3605)
+  const bool do_sparse = SPARSE && b == 0 && (TRANSPOSED ? a.idx_t != nullptr : a.outliers != nullptr);   // reference: batch 0 only (KCU:3605)
   const int ntok = (a.L - tile0 < T) ? (int)(a.L - tile0) : T;
   const unsigned nent = do_sparse ? (unsigned)ntok * (unsigned)a.n_out : 0u;   // entries of the tile
   const unsigned wbase = (unsigned)wave * 32u * (unsigned)a.n_out;             // this wave's first entry
@@ -279,8 +282,16 @@ void score_k_kernel(ScoreKArgs a) {
   auto sparse_fetch_t = [&](int s2, float &val, int &col) {
     const float *bv = a.out_t + (int64_t)s2 * a.max_len;
     const int32_t *bi = a.idx_t + (int64_t)s2 * a.max_len;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(val) : "v"(toff_t), "s"(bv) : "memory");
+    if constexpr (COMPACT) asm volatile("" : "=v"(val));      // (one packed word per entry: defined in place, no load)
+    else asm volatile("global_load_dword %0, %1, %2" : "=v"(val) : "v"(toff_t), "s"(bv) : "memory");
     asm volatile("global_load_dword %0, %1, %2" : "=v"(col) : "v"(toff_t), "s"(bi) : "memory");
+  };
+  // packed entry -> (residual, global channel)
+  auto entry_of = [&](float &val, int &col) {
+    if constexpr (COMPACT) {
+      val = __half2float(__ushort_as_half((unsigned short)((uint32_t)col >> 16)));
+      col = col & 0xffff;
+    }
   };
   // The look-ahead (val, col) registers are a two-set ring like the word sets below: a set is written by
   // asm loads (outside hipcc's vmcnt scoreboard) after the dense section of one unrolled copy of the head
@@ -441,6 +452,7 @@ void score_k_kernel(ScoreKArgs a) {
   // the only other lane that can touch the same (token, head) cell in the same instruction is the other
   // role half's lane of the same token, so the pair is merged into the role-0 lane first.
   auto sparse_step_t = [&](int s2, float val, int col) {
+    entry_of(val, col);
     const bool s_ok = !(role == 1 && (a.n_out & 1) && s2 == 0);
     const int hhE = (col >> 7) - h0;
     const int ch = col & 127;
@@ -581,8 +593,9 @@ void score_k_kernel(ScoreKArgs a) {
       };
       // ---- the outlier entry of this head (sparse_step_t, cut into stages) -------------------------------------------
       const bool sp_on = hh < nsteps && !(KVQ_ABL & 128);          // (wave-uniform)
-      const float sp_val = spv_all[buf & 1];
-      const int sp_col = spc_all[buf & 1];
+      float sp_val = spv_all[buf & 1];
+      int sp_col = spc_all[buf & 1];
+      entry_of(sp_val, sp_col);
       const int sp_hhE = (sp_col >> 7) - h0, sp_ch = sp_col & 127;
       bool sp_use = false;
       float sp_th = 0.f, sp_q1 = 0.f, sp_q2 = 0.f, sp_sn = 0.f, sp_c = 0.f, sp_x = 0.f, sp_xo = 0.f, sp_old = 0.f;
@@ -979,14 +992,14 @@ static int pick_groups(int H, int64_t tiles, int q_len, int max_hpg, int slots) 
   return best;
 }
 
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false>
 static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipStream_t st) {
   constexpr int T = NWAVES * 32;
   ScoreKArgs a = a0;
   const int64_t full_tiles = a.L / T;
   const int rem = (int)(a.L % T);
   const int max_hpg = SPARSE ? kSparseHpg : 1 << 30;
-  static const int slots = workgroup_slots(score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED>, NWAVES * 64, 16 / NWAVES);
+  static const int slots = workgroup_slots(score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT>, NWAVES * 64, 16 / NWAVES);
   a.groups = full_tiles ? pick_groups(a.H, full_tiles, q_len, max_hpg, slots) : 1;
   a.hpg = a.H / a.groups;
   if (full_tiles && a.hpg > max_hpg) return KVQ_EINVAL;   // (no full tile: only the ragged one's head groups exist)
@@ -1006,7 +1019,7 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
   if (!a.trace) return KVQ_EINVAL;
 #endif
-  score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED><<<grid, block, 0, st>>>(a);
+  score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT><<<grid, block, 0, st>>>(a);
   return check_launch();
 }
 
@@ -1023,6 +1036,10 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
   a.tab = tab;
   a.q = q32;   // fp32 copy made by the prep (the sparse phase reads q directly)
   // big tiles (8 waves) once there are enough of them, small tiles for short caches
+  if (a.idx_t != nullptr && a.out_t == nullptr) {     // compact mirror
+    return a.L >= 16384 ? launch_score<BITS, true, 8, true, true>(a, q_len, theta, st)
+                        : launch_score<BITS, true, 4, true, true>(a, q_len, theta, st);
+  }
   if (a.out_t != nullptr) {
     return a.L >= 16384 ? launch_score<BITS, true, 8, true>(a, q_len, theta, st)
                         : launch_score<BITS, true, 4, true>(a, q_len, theta, st);
@@ -1057,9 +1074,9 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
   if ((!q && !tables_ready) || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 ||
       L > max_len || bits < 2 || bits > 4)
     return KVQ_EINVAL;
-  const bool sparse = outliers != nullptr || outliers_t != nullptr;
+  const bool sparse = outliers != nullptr || idx_t != nullptr;     // (idx_t alone: the compact mirror)
   if (sparse && ((outliers && !outlier_idx) || (outliers_t && !idx_t) || n_out <= 0 || n_out > 4096)) return KVQ_EINVAL;
-  if (outliers_t && (int64_t)n_out * max_len * 4 >= (1ll << 32)) return KVQ_EINVAL;   // 32-bit lane offsets
+  if (idx_t && (int64_t)n_out * max_len * 4 >= (1ll << 32)) return KVQ_EINVAL;   // 32-bit lane offsets
   if (L == 0) return KVQ_OK;
   if (!workspace || workspace_bytes < kvq_score_k_workspace_bytes(bits, q_len, H) ||
       reinterpret_cast<uintptr_t>(workspace) % 16)
@@ -1123,10 +1140,10 @@ int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul, const
                                  const float *outliers_t, const int32_t *outlier_idx_t, void *workspace,
                                  size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts, int n_parts,
                                  void *stream) {
-  if (!softmax_parts || (!outliers && !outliers_t) || n_parts != kvq_score_k_softmax_parts(bits, L, 1))
+  if (!softmax_parts || (!outliers && !outlier_idx_t) || n_parts != kvq_score_k_softmax_parts(bits, L, 1))
     return KVQ_EINVAL;
   return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset,
-                     outliers_t ? nullptr : outliers, outliers_t ? nullptr : outlier_idx, n_out, 0, workspace,
+                     outlier_idx_t ? nullptr : outliers, outlier_idx_t ? nullptr : outlier_idx, n_out, 0, workspace,
                      workspace_bytes, stream, softmax_parts, inv_sqrt_hd, n_parts, outliers_t, outlier_idx_t);
 }
 

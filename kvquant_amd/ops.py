@@ -34,6 +34,15 @@ def _i(t, name):
     return _chk(t, torch.int32, name)
 
 
+def _fo(t, name):
+    """optional f32 tensor -> pointer / None (compact formats carry no value array: include/kvq.h)"""
+    return None if t is None else _chk(t, torch.float32, name)
+
+
+def _io(t, name):
+    return None if t is None else _chk(t, torch.int32, name)
+
+
 def _cache_dims(mat, bits):
     if mat.dim() != 3:
         raise ValueError("mat: expected [num_heads, head_dim/32*bits, max_len]")
@@ -167,24 +176,28 @@ def mix_v(bits, p, mat, mul, lut_rows, L, outliers=None, outlier_indices=None, a
     if p.shape[2] != L:
         raise ValueError("vec.shape[2] must equal vcachelen")
     q_len = p.shape[0]
-    n_out = 0 if outliers is None else outliers.shape[1]
+    # (outlier_indices without outliers: COMPACT rows, packed entries in the index array)
+    n_out = 0 if outlier_indices is None else outlier_indices.shape[1]
     with _Dev(p):
         nbytes = _L().kvq_mix_v_workspace_bytes(bits, q_len, H, hd, int(L))
         ws = _workspace(p.device, nbytes)
         _lib.check(_L().kvq_mix_v(
             bits, _f(p, "vec"), _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), q_len, H, hd,
-            int(L), max_len, None if outliers is None else _f(outliers, "outliers"),
-            None if outliers is None else _i(outlier_indices, "outlier_indices"), n_out,
+            int(L), max_len, _fo(outliers, "outliers"), _io(outlier_indices, "outlier_indices"), n_out,
             1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "kvq_mix_v")
 
 
 def _mirror(outliers_t, outlier_indices_t, thr_k, max_len):
     """(ptr, ptr) of the optional token-contiguous K outlier mirror [2*thr_k, max_len], or (None, None)"""
-    if outliers_t is None:
+    if outlier_indices_t is None:
+        if outliers_t is not None:
+            raise ValueError("the outlier mirror needs its index array")
         return None, None
-    if tuple(outliers_t.shape) != (2 * thr_k, max_len) or tuple(outlier_indices_t.shape) != (2 * thr_k, max_len):
+    if tuple(outlier_indices_t.shape) != (2 * thr_k, max_len) or \
+            (outliers_t is not None and tuple(outliers_t.shape) != (2 * thr_k, max_len)):
         raise ValueError("the outlier mirror must be [%d, %d]" % (2 * thr_k, max_len))
-    return _f(outliers_t, "outliers_t"), _i(outlier_indices_t, "outlier_indices_t")
+    # (index array alone: the COMPACT mirror, packed entries fp16 residual << 16 | channel)
+    return _fo(outliers_t, "outliers_t"), _i(outlier_indices_t, "outlier_indices_t")
 
 
 def append_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, thr_k, col, outliers_t=None,
@@ -236,7 +249,7 @@ def pack_k_fused(bits, mat, lut, lut_off, x, lo, hi, outliers, outlier_indices, 
     with _Dev(mat):
         _lib.check(_L().kvq_pack_k_fused(bits, _i(mat, "mat"), _f(lut, "lookup_table"), _f(lut_off, "lut_off"),
                                          _f(x, "newvec"), _f(lo, "lower"), _f(hi, "upper"),
-                                         _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"),
+                                         _fo(outliers, "outliers"), _io(outlier_indices, "outlier_indices"),
                                          int(thr_k), H, hd, max_len, int(col0), int(S),
                                          *_mirror(outliers_t, outlier_indices_t, thr_k, max_len), _stream()),
                    "kvq_pack_k_fused")
@@ -250,7 +263,7 @@ def pack_v_fused(bits, mat, lut_rows, lut_sorted, x, outliers, outlier_indices, 
         raise ValueError("x must be [H, hd, S]")
     with _Dev(mat):
         _lib.check(_L().kvq_pack_v_fused(bits, _i(mat, "mat"), _f(lut_rows, "lookup_table"), _f(lut_sorted, "lut"),
-                                         _f(x, "newvec"), _f(outliers, "outliers"),
+                                         _f(x, "newvec"), _fo(outliers, "outliers"),
                                          _i(outlier_indices, "outlier_indices"), int(thr_k), H, hd, max_len,
                                          int(col0), int(S), _vnorm(norm), _stream()), "kvq_pack_v_fused")
 
@@ -503,13 +516,40 @@ def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows,
     return sink_probs
 
 
+# ---- token-sharded single stream ---------------------------------------------------------------------------------
+def score_k_tables(bits, q, lut, H):
+    """query-premultiplied K tables into the score workspace without an append (kvq_score_k_tables); returns the
+    workspace tensor for score_k_prepared[_softmax]"""
+    qp, qh = _act(q, "q")
+    with _Dev(lut):
+        nbytes = _L().kvq_score_k_workspace_bytes(bits, 1, H)
+        ws = _workspace(lut.device, nbytes, slot="score")
+        _lib.check(_L().kvq_score_k_tables(bits, qp, qh, _f(lut, "lookup_table"), H, 128, ws.data_ptr(), ws.numel(),
+                                           _stream()), "kvq_score_k_tables")
+    return ws
+
+
+def softmax_stats(parts, n_parts, H, stats):
+    """(max, normaliser) of every head's scaled scores from the score kernel's partials -> stats f32 [H, 2]"""
+    with _Dev(stats):
+        _lib.check(_L().kvq_softmax_stats(parts.data_ptr(), int(n_parts), int(H), _f(stats, "stats"), _stream()),
+                   "kvq_softmax_stats")
+
+
+def combine_shards(packed, n_shards, H, hd, out):
+    """exact merge of n_shards records [H*hd out | H x (M, Z)] (f32, contiguous) -> out f32 [1, H, hd]"""
+    with _Dev(out):
+        _lib.check(_L().kvq_combine_shards(_f(packed, "packed"), int(n_shards), int(H), int(hd), _f(out, "out"), _stream()),
+                   "kvq_combine_shards")
+
+
 # ---- one decode token through one layer, one library call -----------------------------------------------------------
 def make_layer(kc, vc, table, lut_off):
     """struct kvq_layer for a (QuantK, QuantV) pair: every pointer of the layer's compressed cache, built once and
     cached by the caller (the buffers are preallocated and never move).  Returns (struct, keep-alive tuple)."""
     H, hd, max_len = _cache_dims(kc.kcache, kc.bits)
     thr_k = kc.num_outliers // 2
-    if _mirror(kc.outliers_t, kc.outlier_indices_t, thr_k, max_len)[0] is None:
+    if _mirror(kc.outliers_t, kc.outlier_indices_t, thr_k, max_len)[1] is None:
         raise ValueError("decode_step needs the token-contiguous outlier mirror")
     vn = vc.vnorm_args()
     vstruct = None
@@ -521,10 +561,10 @@ def make_layer(kc, vc, table, lut_off):
     ly = _lib.Layer(
         kc.bits, H, hd, thr_k, max_len, float(kc.rope_theta), int(kc.first_few_fp16),
         _i(kc.kcache, "kcache"), _f(kc.lookup_table, "lookup_table"), _f(lut_off, "lut_off"),
-        _f(kc.outlier_threshold_lower, "lower"), _f(kc.outlier_threshold_upper, "upper"), _f(kc.outliers, "outliers"),
-        _i(kc.outlier_indices, "outlier_indices"), _f(kc.outliers_t, "outliers_t"), _i(kc.outlier_indices_t, "outlier_indices_t"),
+        _f(kc.outlier_threshold_lower, "lower"), _f(kc.outlier_threshold_upper, "upper"), _fo(kc.outliers, "outliers"),
+        _io(kc.outlier_indices, "outlier_indices"), _fo(kc.outliers_t, "outliers_t"), _i(kc.outlier_indices_t, "outlier_indices_t"),
         None if kc.lut_ends is None else _f(kc.lut_ends, "lut_ends"), None if table is kc.lookup_table else _f(table, "lut_score"),
-        _i(vc.vcache, "vcache"), _f(vc.lookup_table, "lookup_table"), _f(vc.lut, "lut"), _f(vc.outliers, "outliers"),
+        _i(vc.vcache, "vcache"), _f(vc.lookup_table, "lookup_table"), _f(vc.lut, "lut"), _fo(vc.outliers, "outliers"),
         _i(vc.outlier_indices, "outlier_indices"), None if vstruct is None else ctypes.pointer(vstruct),
         None if mix is vc.lookup_table else _f(mix, "lookup_table2"))
     return ly, (vstruct, table, lut_off, mix)

@@ -162,20 +162,30 @@ class StreamPipeline:
         return finals if r == 0 else []
 
 
-def token_sharded_step(shard_fn, group=None):
+def token_sharded_step(shard_fn, record=None, group=None):
     """One decode step of ONE stream whose context is split along the token axis over the ranks of `group`
     (`kvquant_amd.cache.shard_attention` on each rank's shard): every rank streams only its L / N cached tokens, then
-    ONE all-gather of [H, hd + 2] floats per layer (17 KB at the 7B shape; flat over the direct xGMI links) carries the
-    shards' outputs and softmax statistics, and every rank forms the exact merged output (`combine_shards`).
-    shard_fn() -> (out [1, H, hd], M [H], Z [H]) for this rank's shard.  Returns the merged [1, H, hd] on every rank."""
+    ONE all-gather of the shard records per layer ([H*hd + 2H] floats = 16.6 KB at the 7B shape; flat over the direct
+    xGMI links) carries the shards' outputs and softmax statistics, and every rank forms the exact merged output.
+    shard_fn(record) -> (out [1, H, hd], M [H], Z [H]) for this rank's shard.  GPU path: pass `record` (f32
+    [cache.shard_record_floats(H, hd)] on the GPU) -- shard_attention writes into it, it is gathered as it is and the
+    merge is one library launch (kvq_combine_shards): no torch arithmetic on the data path.  record = None (CPU
+    tensors, the gloo tests): the torch formula of cache.combine_shards.  Returns the merged [1, H, hd] on every rank."""
+    from . import ops
     from .cache import combine_shards
-    out, M, Z = shard_fn()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    out, M, Z = shard_fn(record)
+    H, hd = out.shape[1], out.shape[2]
     if world == 1:
         return out
+    if record is not None and record.is_cuda:
+        gathered = torch.empty(world * record.numel(), dtype=torch.float32, device=record.device)
+        dist.all_gather_into_tensor(gathered, record, group=group)
+        merged = torch.empty((1, H, hd), dtype=torch.float32, device=record.device)
+        ops.combine_shards(gathered, world, H, hd, merged)
+        return merged
     packed = torch.cat((out[0], M[:, None], Z[:, None]), dim=-1).contiguous()          # [H, hd + 2]
     bufs = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(bufs, packed, group=group)
     allp = torch.stack(bufs)                                                            # [R, H, hd + 2]
-    hd = out.shape[-1]
     return combine_shards(allp[:, None, :, :hd], allp[:, :, hd], allp[:, :, hd + 1])

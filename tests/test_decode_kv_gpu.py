@@ -246,14 +246,17 @@ def test_fused_sinks_match_torch_glue(bits, prefill, max_len):
         assert (out - out_ref).abs().max().item() <= 2e-3 * scale_o, step
 
 
-@pytest.mark.parametrize("bits,S,split,sinks", [(4, 700, 300, 0), (4, 9000, 4096, 0), (3, 1200, 640, 5), (4, 40, 10, 0)])
-def test_token_sharded_attention_matches_unsharded(bits, S, split, sinks):
-    """cache.shard_attention over two shards of a context split along the token axis (positions of the second shard
-    start at `split`; the new token is appended to it) + combine_shards against decode_kv on the unsharded cache:
-    the same attention output to the decode tolerance (probabilities are rounded to fp16 per shard)."""
+@pytest.mark.parametrize("bits,S,split", [(4, 700, 300), (4, 9000, 4096), (3, 1200, 640), (2, 40, 10)])
+def test_token_sharded_attention_matches_unsharded(bits, S, split):
+    """cache.shard_attention over the shards of a context split along the token axis (positions of the second shard
+    start at `split`; the new token is appended to it; a third shard is EMPTY) merged by kvq_combine_shards on the
+    concatenated records -- what one all-gather per layer delivers -- against decode_kv on the unsharded cache: the
+    same attention output to the decode tolerance (probabilities are rounded to fp16 per shard).  The torch formula
+    (cache.combine_shards, used by the CPU tests) must agree with the kernel."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from kvquant_amd.cache import QuantK, QuantV, decode_kv, shard_attention, combine_shards
+    from kvquant_amd import ops
+    from kvquant_amd.cache import QuantK, QuantV, decode_kv, shard_attention, combine_shards, shard_record_floats
     dev = torch.device("cuda:0")
     H, HD, C = decode_check.H, decode_check.HD, decode_check.C
     quant, scale, shift = decode_check.quantizer(bits, seed=21 + bits)
@@ -263,11 +266,10 @@ def test_token_sharded_attention_matches_unsharded(bits, S, split, sinks):
 
     def make(ks, vs, max_len):
         kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
-                  sparsity_threshold=0.99, first_few_fp16=sinks, device=dev)
+                  sparsity_threshold=0.99, first_few_fp16=0, device=dev)
         kc, vc = QuantK(rope_theta=10000.0, **kw), QuantV(**kw)
         kc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
         vc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
-        kc.klen = vc.vlen = sinks
         if ks.shape[-1]:
             kc.parallel_pack(ks.contiguous())
             vc.parallel_pack(vs.contiguous())
@@ -276,17 +278,29 @@ def test_token_sharded_attention_matches_unsharded(bits, S, split, sinks):
     full = make(k, v, (S + 64 + 63) // 64 * 64)
     s0 = make(k[:, :, :split], v[:, :, :split], (split + 63) // 64 * 64)
     s1 = make(k[:, :, split:], v[:, :, split:], (S - split + 64 + 63) // 64 * 64)
+    s2 = make(k[:, :, :0], v[:, :, :0], 64)
+    nrec = shard_record_floats(H, HD)
     for step in range(2):
         q = torch.randn(H, HD, generator=g).half().to(dev)
         kn = (torch.randn(C, generator=g) * scale * 1.3 + shift).half().to(dev)
         vn = (torch.randn(C, generator=g) * 1.7).half().to(dev)
         ref, _ = decode_kv(full[0], full[1], q, kn, vn)
-        o0, m0, z0 = shard_attention(s0[0], s0[1], q, pos_base=0)
-        o1, m1, z1 = shard_attention(s1[0], s1[1], q, kn, vn, pos_base=split)
-        out = combine_shards(torch.stack((o0, o1)), torch.stack((m0, m1)), torch.stack((z0, z1)))
+        gathered = torch.empty(3 * nrec, device=dev)
+        o0, m0, z0 = shard_attention(s0[0], s0[1], q, pos_base=0, record=gathered[:nrec])
+        o1, m1, z1 = shard_attention(s1[0], s1[1], q, kn, vn, pos_base=split, record=gathered[nrec:2 * nrec])
+        o2, m2, z2 = shard_attention(s2[0], s2[1], q, pos_base=S + 100, record=gathered[2 * nrec:])
+        assert bool(torch.isinf(m2).all()) and float(z2.abs().max()) == 0.0
+        out = torch.empty(1, H, HD, device=dev)
+        ops.combine_shards(gathered, 3, H, HD, out)
+        out_t = combine_shards(torch.stack((o0, o1, o2)), torch.stack((m0, m1, m2)), torch.stack((z0, z1, z2)))
         torch.cuda.synchronize()
         scale_o = ref.abs().max().item() + 1e-6
         assert (out - ref).abs().max().item() <= 2e-3 * scale_o, step
+        assert (out - out_t).abs().max().item() <= 1e-5 * scale_o, step
+    with pytest.raises(ValueError):          # fp16 sink tokens are not part of the sharded path (no silent drop)
+        kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=64, include_sparse=True,
+                  sparsity_threshold=0.99, first_few_fp16=5, device=dev)
+        shard_attention(QuantK(rope_theta=10000.0, **kw), QuantV(**kw), q)
 
 
 @pytest.mark.parametrize("bits,sinks,L0", [(4, 0, 40), (3, 5, 300), (2, 0, 40)])

@@ -135,7 +135,7 @@ def _token_shard_worker(rank, world, port, q):
         per = L // world
         sl = slice(rank * per, (rank + 1) * per if rank < world - 1 else L)
 
-        def shard_fn():                                        # plain-torch stand-in for cache.shard_attention
+        def shard_fn(record=None):                             # plain-torch stand-in for cache.shard_attention
             ss, vv = s[:, sl], v[:, sl]
             M = ss.max(dim=-1).values
             e = torch.exp(ss - M[:, None])
@@ -156,7 +156,7 @@ def test_token_sharded_step_merges_exactly(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + world
+    port = _free_port()
     procs = [ctx.Process(target=_token_shard_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -211,8 +211,9 @@ def check_linear(path, kernel_substr="score_k_kernel", skip=None):
 
 
 def is_jit(name):
-    """the mirror variants (TRANSPOSED = true: ...ELb1EEEvNS_10ScoreKArgsE): loads in flight across loop iterations"""
-    return re.search(r"ELb1EEEvNS_", name) is not None
+    """the mirror variants (TRANSPOSED = true, the 4th template argument of score_k_kernel<BITS, SPARSE, NWAVES,
+    TRANSPOSED, COMPACT>): loads in flight across loop iterations"""
+    return re.search(r"score_k_kernelILi\dELb[01]ELi\dELb1ELb[01]EEE", name) is not None
 
 
 def check(path, kernel_substr="score_k_kernel"):
