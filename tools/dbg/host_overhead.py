@@ -6,7 +6,7 @@ import bench
 from kvquant_amd import sharding
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(0)
-ctx, nl, steps = 131072, 8, 20
+ctx, nl, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 131072, 8, 20
 max_len = (ctx + 64 + 63) // 64 * 64
 layers = []
 for li in range(nl):
