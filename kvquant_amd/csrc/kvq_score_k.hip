@@ -183,7 +183,7 @@ void score_k_kernel(ScoreKArgs a) {
   constexpr bool JIT = KVQ_K_JIT && TRANSPOSED && !KVQ_K_SPARSE_AFTER && PF == 2;
   constexpr bool WEAVE = KVQ_K_WEAVE && JIT && BITS == 4;
   // (WEAVE: the table pieces are issued behind the first two word re-loads of the head)
-  constexpr int JIT_OPS = 2 * BITS + (COMPACT ? 1 : 2) - (WEAVE ? 2 : 0);
+  constexpr int JIT_OPS = 2 * BITS + (COMPACT ? 1 : 2) - (WEAVE ? 2 : 0) - ((KVQ_ABL & 1024) ? BITS : 0);
   // VMEM operations of one look-ahead step that EVERY wave issues (waves with an extra table piece wait
   // for one more than they need to)
   constexpr int STEP_OPS = 2 * BITS + TAB_DMA / NWAVES;
@@ -282,6 +282,10 @@ void score_k_kernel(ScoreKArgs a) {
   auto sparse_fetch_t = [&](int s2, float &val, int &col) {
     const float *bv = a.out_t + (int64_t)s2 * a.max_len;
     const int32_t *bi = a.idx_t + (int64_t)s2 * a.max_len;
+#if KVQ_ABL & 512
+    asm volatile("v_mov_b32 %0, 1.0\n\tv_and_b32 %1, 0xfff, %2" : "=v"(val), "=v"(col) : "v"(toff_t));
+    return;
+#endif
     if constexpr (COMPACT) asm volatile("" : "=v"(val));      // (one packed word per entry: defined in place, no load)
     else asm volatile("global_load_dword %0, %1, %2" : "=v"(val) : "v"(toff_t), "s"(bv) : "memory");
     asm volatile("global_load_dword %0, %1, %2" : "=v"(col) : "v"(toff_t), "s"(bi) : "memory");
@@ -718,8 +722,16 @@ void score_k_kernel(ScoreKArgs a) {
         if constexpr (JIT) {
           // rows j of the lo / hi halves are consumed: their registers take the same rows of head hh+2
           asm volatile("" ::"v"(elo), "v"(olo), "v"(ehi), "v"(ohi));
+#if KVQ_ABL & 256
+          asm volatile("v_mov_b32 %0, %1" : "=v"(wlo[j]) : "v"(woff));
+          asm volatile("v_mov_b32 %0, %1" : "=v"(whi[j]) : "v"(woff));
+#elif KVQ_ABL & 1024
+          asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(wlo[j]) : "v"(woff), "s"(jit_row + j * a.max_len) : "memory");
+          asm volatile("v_mov_b32 %0, %1" : "=v"(whi[j]) : "v"(woff));
+#else
           asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(wlo[j]) : "v"(woff), "s"(jit_row + j * a.max_len) : "memory");
           asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(whi[j]) : "v"(woff), "s"(jit_row + hi_words + j * a.max_len) : "memory");
+#endif
         }
         constexpr int LKB = KVQ_K_LKB, NA = KVQ_K_NACC;
         static_for<0, 8 / LKB>([&](auto HH) {

@@ -41,6 +41,10 @@ back = st[:, :, 1:, 0] - st[:, :, :-1, 5]
 print("  loop back-edge %.1f" % back.mean())
 tot = st[:, :, 31, 5] - st[:, :, 0, 0]
 print("head loop total per wave: mean %.0f min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
+_tl = trace[1024 * 8 * 32 * 8:].view(1024, 8, 8).cpu()[:512].double()
+_us = ((_tl[..., 2] - _tl[..., 1]) / 100.0)
+print("shader clock during the head loop: %.0f MHz (s_memtime cycles of the loop / its s_memrealtime span, mean over waves)"
+      % (tot / _us).mean())
 # kernel-level timeline (100 MHz wall clock): entry, loop start, loop end, exit of every wave; where it ran
 nb = 512 + 32 if (tl[512:544, 0, 0] != 0).all() else 512
 T = tl[:nb, :, :4].double() / 100.0            # us

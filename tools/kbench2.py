@@ -57,7 +57,10 @@ def run(bits, L, iters=int(os.environ.get("KB_ITERS", "100")), nrot=2):
 
     def vcall(i):
         d = caches[i % nrot]
-        ops.mix_v(bits, state["p"].unsqueeze(0), d["v"], out, d["rows"], L, d["vvals"], d["vidx"], accumulate=False)
+        if os.environ.get("KB_NOSPARSE"):
+            ops.mix_v(bits, state["p"].unsqueeze(0), d["v"], out, d["rows"], L, None, None, accumulate=False)
+        else:
+            ops.mix_v(bits, state["p"].unsqueeze(0), d["v"], out, d["rows"], L, d["vvals"], d["vidx"], accumulate=False)
 
     def vfcall(i):
         d = caches[i % nrot]
