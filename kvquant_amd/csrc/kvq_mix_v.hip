@@ -26,8 +26,10 @@
 //     range; slots are summed through LDS once at the end and every workgroup
 //     writes its channel slice of one partial slab; a second small kernel adds
 //     the slabs into `mul` in a fixed order (deterministic);
-//   * the sparse residuals of the range are scattered into an LDS accumulator
-//     (32.32 fixed-point ds_add_u64) by the same workgroup after its dense loop.
+//   * the sparse residuals of the range that fall into the workgroup's channel
+//     slice are scattered into an LDS accumulator (32.32 fixed-point ds_add_u64:
+//     exact, order independent) before or after its dense loop and added to the
+//     dense sums in registers: one partial slab per workgroup, nothing else.
 // Needs max_len % 4 == 0 (16-byte DMA source alignment); other shapes take the
 // row-per-lane fallback in kvq_mix_v_rows.h.
 // Algorithmic HBM bytes per cached token: C*bits/8 + 4*2^bits (codebook row)
@@ -434,7 +436,7 @@ __device__ __forceinline__ float prob_of(float raw, float inv, float M, float rZ
 template <int BITS, bool FUSED>
 __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   using Cfg = VCfg<BITS>;
-  constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT;
+  constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT, CHL = Cfg::CHL;
   __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B + (FUSED ? Cfg::MZ_B : 0) + KVQ_PAD_LDS];  // static: LDS offsets fold into ds immediates
   unsigned char *stage0 = smem;
 
@@ -446,8 +448,17 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   const int hf = __builtin_amdgcn_readfirstlane((tid / Cfg::UW) % Cfg::HALVES);   // which half of the unit's channels
   const int lu = tid % (Cfg::UW * Cfg::HALVES);                                   // lane within the slot
   const int sl = tid / (Cfg::UW * Cfg::HALVES);   // token slot (wave-uniform)
-  const int g = blockIdx.x % a.groups;
-  const int range = blockIdx.x / a.groups;
+  // block -> (range, unit group).  The workgroups of one range share its codebook rows and its outlier entries: they are
+  // numbered 8 apart, so that they run on the same XCD (block b goes to XCD b % 8) back to back and the second one
+  // finds those lines in that XCD's L2.  (Last, partial chunk of ranges: any bijection.)
+  int g, range;
+  {
+    const int G = a.groups, n_ranges = (int)gridDim.x / G;
+    const int chunk = (int)blockIdx.x / (8 * G), r = (int)blockIdx.x % (8 * G);
+    const int nr = (n_ranges - 8 * chunk < 8) ? (n_ranges - 8 * chunk) : 8;
+    g = r / nr;
+    range = 8 * chunk + r % nr;
+  }
   const int b = blockIdx.z;
   const int C = a.H * kHeadDim;
   const int u0 = g * Cfg::UW;
@@ -462,19 +473,19 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   const int n_chunks = (int)((t1 - t0 + CT - 1) / CT);
 
   const uint32_t lds0 = lds_addr(smem);
-  const DmaLane dl = make_dma_lane<BITS>();
+  DmaLane dl = make_dma_lane<BITS>();
   const bool sparse = (a.idx != nullptr) && (b == 0);        // reference: batch 0 only (KCU:3675)
   // COMPACT rows (opt-in format): no value array, `idx` holds packed entries fp16 residual << 16 | channel
   const bool compact = a.outliers == nullptr;
-  // The sparse phase is bound by memory latency (VALU and LDS idle), the dense loop by the LDS pipe.  Half of the
+  // The outlier phase is bound by memory latency (VALU and LDS idle), the dense loop by the look-ups.  Half of the
   // workgroups run it BEFORE their dense loop, the other half after it: wherever two workgroups share a CU in either
-  // order, one's latency-bound phase hides behind the other's look-ups (all of them at the end: 19 % of the kernel
-  // with nothing to overlap; all of them at the start: every workgroup stalls at once).
+  // order, one's latency-bound phase hides behind the other's look-ups (nuq3 p.V + reduce at 128K: 84 us alternating,
+  // 91 us with every phase at the end).  The groups of a range (blocks 8 apart) have the same parity: they read the
+  // range's entries at about the same time.
 #ifndef KVQ_V_SPFIRST
-#define KVQ_V_SPFIRST 1   // 0: always after the loop; 1: odd workgroups first; 2: the second half of the grid first
+#define KVQ_V_SPFIRST 1   // 0: always after the loop; 1: odd workgroups first
 #endif
-  const bool sparse_first = !FUSED && sparse &&
-                            (KVQ_V_SPFIRST == 1 ? (blockIdx.x & 1) : (KVQ_V_SPFIRST == 2 ? (blockIdx.x >= gridDim.x / 2) : 0));
+  const bool sparse_first = !FUSED && sparse && KVQ_V_SPFIRST && (blockIdx.x & 1);
   if (!sparse_first) issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
   const float2 *mz = reinterpret_cast<const float2 *>(smem + Cfg::SMEM_B);   // FUSED: (max, normaliser) per head
   float myM = 0.f, myZ = 1.f;                                                  // ... of the head this lane converts for
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     *pp = (c0 + (tid % CT) < t1) ? prob_of(x, a.inv, myM, myZ) : 0.f;
   };
   if constexpr (FUSED) convert_p(0, t0);   // (visible after the first chunk's barrier)
-  const DmaFast df = make_dma_fast<BITS>(a, dl);
+  DmaFast df = make_dma_fast<BITS>(a, dl);
   // chunks whose DMA needs no clamps (see issue_fast): all that start at or before `fast_end`
   int64_t fast_end = (a.max_len < a.L ? a.max_len : a.L) - CT;
   if (n_units_valid != Cfg::UW) fast_end = -1;
@@ -573,38 +584,28 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_r0)::"memory");
   }
 #endif
+  // Outlier entries.  Workgroup (range, group g) takes ALL tokens of its range and the entries whose channel belongs to
+  // ITS units: the sums land in the channel slice its dense partial covers -- no separate outlier slabs (round 2: one
+  // 16 KB slab per workgroup, written here and read back by the reduce kernel: 32 MB of the launch's traffic at 128K)
+  // and only this group's heads of the probabilities to stage.  The entries are read once per group (from the L2: see
+  // the block numbering above).  The phase runs after the dense loop (32.32 fixed-point LDS adds: exact, order
+  // independent); nothing of it is live across the loop.
   auto sparse_phase = [&]() {
-    // LDS after the dense loop: [0, SP_P_B) the probabilities of this workgroup's token share for all heads,
-    // [SP_P_B, ...) the fixed-point accumulators.  Staging p (coalesced, independent of the entries) removes the
-    // second dependent memory round trip of the phase (entry -> head -> p gather): the phase is pure latency --
-    // measured 25.8k cycles per wave = 19 % of the kernel at 128K before, with two rounds of two round trips.
+    // LDS (aliases the pipeline stages): [0, SP_P_B) the probabilities of a block of the range's tokens for the group's
+    // heads, [SP_P_B, ...) the fixed-point accumulators of the group's channels.  Staging p (coalesced, independent of the
+    // entries) removes the second dependent memory round trip (entry -> head -> p gather): the phase is pure latency.
     float *pl = reinterpret_cast<float *>(smem);
     long long *sacc = reinterpret_cast<long long *>(smem + Cfg::SP_P_B);
-    constexpr int SCH = (Cfg::SMEM_B - Cfg::SP_P_B) / 8;     // channels per pass
-    const int64_t share = ((t1 - t0) + a.groups - 1) / a.groups;
-    const int64_t s0 = t0 + (int64_t)g * share;
-    const int64_t s1 = (s0 + share < t1) ? (s0 + share) : t1;
-    const int ns = s1 > s0 ? (int)(s1 - s0) : 0;             // tokens of the share
-    const unsigned nent = (unsigned)ns * (unsigned)a.n_out;  // < 2^31
-    const float *ov = compact ? reinterpret_cast<const float *>(a.idx + s0 * a.n_out) : a.outliers + s0 * a.n_out;
-    const int32_t *oi = a.idx + s0 * a.n_out;
-    const float *p0 = (FUSED ? a.scores : a.p) + s0;   // FUSED: raw scores, converted on the way
-    float *sslab = a.sparse_partial + (int64_t)blockIdx.x * C;
-    const bool staged = ns <= 320 && (int64_t)(ns | 1) * a.H * 4 <= Cfg::SP_P_B;
-    constexpr int RB = KVQ_V_RB;    // entries per lane per round, all loads of a round in flight together (24: a 272-token share at n_out = 42 in one round)
-    auto load_round = [&](unsigned base, int (&row)[RB], float (&val)[RB]) {
-#pragma unroll
-      for (int j = 0; j < RB; j++) {
-        const unsigned e = base + j * Cfg::NT + tid;
-        const unsigned ec = e < nent ? e : (nent ? nent - 1 : 0);
-        // (branch-free on purpose: a branch in here makes hipcc lose the wave-uniformity of the DMA bases further down.
-        //  Compact rows: `ov` aliases the packed array, the second load hits the line the first one fetched.)
-        const uint32_t w = (uint32_t)oi[ec];
-        const float fv = ov[ec];
-        row[j] = compact ? (int)(w & 0xffffu) : (int)w;
-        val[j] = compact ? __half2float(__ushort_as_half((unsigned short)(w >> 16))) : fv;
-      }
-    };
+    static_assert((Cfg::SMEM_B - Cfg::SP_P_B) / 8 >= Cfg::UW * CH, "accumulators of all the group's channels in one pass");
+    const int c_lo = u0 * CH;                                  // the group's channels: [c_lo, c_lo + cn)
+    const int cn = n_units_valid * CH;
+    const int HWv = (n_units_valid + Cfg::UPH - 1) / Cfg::UPH; // its heads: [h0, h0 + HWv)
+    constexpr int RB = KVQ_V_RB;    // entries per lane per round, all loads of a round in flight together
+    // token blocks: the entries of a block fit one round (24 x 512 / 42 = 292 tokens), its probabilities the stage
+    int sb = a.n_out > 0 ? (RB * Cfg::NT) / a.n_out : 0;
+    if (sb > 320) sb = 320;
+    if (sb > Cfg::SP_P_B / (4 * HWv) - 1) sb = Cfg::SP_P_B / (4 * HWv) - 1;
+    if (sb < 1) return;
 #if KVQ_TRACE
     auto sstamp = [&](int k) {
       unsigned long long tt;
@@ -613,86 +614,133 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       tr_prev = (unsigned)tt;
     };
 #endif
-    int row[RB];
-    float val[RB];
-    if (nent) load_round(0, row, val);         // in flight while the probabilities are staged
-    const int nsp = ns | 1;                     // odd row stride: consecutive heads fall into different LDS banks
-    if (staged) {
-      // wave w stages heads w, w+8, ...; lanes along the tokens (coalesced); all of a lane's loads in flight together
-      const int wv = tid >> 6, ln = tid & 63;
-      for (int hb = 0; hb < a.H; hb += 32) {
-        float v[4][5];
+    for (int64_t b0 = t0; b0 < t1; b0 += sb) {
+      const int ns = (t1 - b0 < sb) ? (int)(t1 - b0) : sb;     // tokens of the block
+      const unsigned nent = (unsigned)ns * (unsigned)a.n_out;  // <= RB * NT
+      const float *ov = compact ? reinterpret_cast<const float *>(a.idx + b0 * a.n_out) : a.outliers + b0 * a.n_out;
+      const int32_t *oi = a.idx + b0 * a.n_out;
+      const float *p0 = (FUSED ? a.scores : a.p) + (int64_t)h0 * a.L + b0;   // FUSED: raw scores, converted on the way
+      int row[RB];
+      float val[RB];
+      // (an opaque copy of the thread id per block: otherwise hipcc hoists the 24 entry -> token divisions out of the
+      //  block loop and spills them)
+      unsigned tid_b = tid;
+      asm volatile("" : "+v"(tid_b));
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-          for (int m = 0; m < 5; m++) {
-            const int h = hb + wv + 8 * k, tl = ln + 64 * m;
-            v[k][m] = (h < a.H && tl < ns) ? p0[(int64_t)h * a.L + tl] : 0.f;
-          }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-          for (int m = 0; m < 5; m++) {
-            const int h = hb + wv + 8 * k, tl = ln + 64 * m;
-            if (h < a.H && tl < ns) pl[h * nsp + tl] = (FUSED && !(KVQ_V_DBG & 128)) ? prob_of(v[k][m], a.inv, mz[h].x, mz[h].y) : v[k][m];
-          }
+      for (int j = 0; j < RB; j++) {
+        const unsigned e = j * Cfg::NT + tid_b;
+        const unsigned ec = e < nent ? e : nent - 1;
+        // (branch-free on purpose: a branch in here makes hipcc lose the wave-uniformity of the DMA bases further down.
+        //  Compact rows: `ov` aliases the packed array, the second load hits the line the first one fetched.)
+        const uint32_t w = (uint32_t)oi[ec];
+        const float fv = ov[ec];
+        row[j] = compact ? (int)(w & 0xffffu) : (int)w;
+        val[j] = compact ? __half2float(__ushort_as_half((unsigned short)(w >> 16))) : fv;
       }
-    }
-    for (int c0 = 0; c0 < C; c0 += SCH) {
-      const int cn = (C - c0 < SCH) ? (C - c0) : SCH;
-      for (int i = tid; i < cn; i += Cfg::NT) sacc[i] = 0;
+      const int nsp = ns | 1;                     // odd row stride: consecutive heads fall into different LDS banks
+      {
+        // wave w stages heads w, w+8, ...; lanes along the tokens (coalesced); all of a lane's loads in flight together
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int hb = 0; hb < HWv; hb += 32) {
+          float v[4][5];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+              const int hh = hb + wv + 8 * k, tl = ln + 64 * m;
+              v[k][m] = (hh < HWv && tl < ns) ? p0[(int64_t)hh * a.L + tl] : 0.f;
+            }
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+              const int hh = hb + wv + 8 * k, tl = ln + 64 * m;
+              if (hh < HWv && tl < ns)
+                pl[hh * nsp + tl] = (FUSED && !(KVQ_V_DBG & 128)) ? prob_of(v[k][m], a.inv, mz[h0 + hh].x, mz[h0 + hh].y) : v[k][m];
+            }
+        }
+      }
 #if KVQ_TRACE
       sstamp(6);
 #endif
-      __syncthreads();
+      __syncthreads();                            // staged probabilities visible
 #if KVQ_TRACE
       sstamp(7);
 #endif
-      for (unsigned base = 0; base < nent; base += RB * Cfg::NT) {
-        if (base || c0) load_round(base, row, val);
-        float pt[RB];
 #pragma unroll
-        for (int j = 0; j < RB; j++) {
-          const unsigned e = base + j * Cfg::NT + tid;
-          const unsigned ec = e < nent ? e : nent - 1;
-          const unsigned tl = __umulhi(ec, a.n_out_magic);
-          unsigned h = (unsigned)row[j] >> 7;
-          h = h < (unsigned)a.H ? h : (unsigned)a.H - 1u;
-          pt[j] = staged ? pl[h * nsp + tl]
-                         : (FUSED ? prob_of(p0[(int64_t)h * a.L + tl], a.inv, mz[h].x, mz[h].y) : p0[(int64_t)h * a.L + tl]);
-        }
-#pragma unroll
-        for (int j = 0; j < RB; j++) {
-          const unsigned e = base + j * Cfg::NT + tid;
-          const unsigned rel = (unsigned)(row[j] - c0);
-          if (e < nent && rel < (unsigned)cn) {
-            // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
-            const float x = val[j] * pt[j];
-            const float fl = floorf(x);
-            const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
-            const int hi = (int)fl;
-            const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
-            atomicAdd(reinterpret_cast<unsigned long long *>(&sacc[rel]), fx);
-          }
+      for (int j = 0; j < RB; j++) {
+        const unsigned e = j * Cfg::NT + tid_b;
+        const unsigned ec = e < nent ? e : nent - 1;
+        const unsigned tl = __umulhi(ec, a.n_out_magic);
+        const unsigned rel = (unsigned)(row[j] - c_lo);          // channel within the group
+        const bool mine = e < nent && rel < (unsigned)cn;
+        const unsigned hh = mine ? (rel >> 7) : 0u;
+        const float pt = pl[hh * nsp + tl];
+        if (mine) {
+          // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
+          const float x = val[j] * pt;
+          const float fl = floorf(x);
+          const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
+          const int hi = (int)fl;
+          const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
+          atomicAdd(reinterpret_cast<unsigned long long *>(&sacc[rel]), fx);
         }
       }
 #if KVQ_TRACE
       sstamp(8);
 #endif
-      __syncthreads();
+      __syncthreads();                            // the stage may be rewritten / the sums are complete
 #if KVQ_TRACE
       sstamp(9);
 #endif
-      for (int i = tid; i < cn; i += Cfg::NT) sslab[c0 + i] = (float)((double)sacc[i] * (1.0 / 4294967296.0));
-      __syncthreads();   // (frees the accumulators for the next pass)
     }
-    };
+  };
+  // the lane that stores a unit half's channels at the end (slot 0), its slice of the partial slab and of the accumulators
+  // (computed from an opaque copy of the thread id wherever it is needed, so that none of it stays live across the dense
+  //  loop, which runs at the 128-VGPR limit: a spill reload inside the loop waits for vmcnt(0) and drains the DMAs)
+  struct Slice { bool writer; float *dst; long long *sacc; };
+  auto slice_of = [&]() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int ul_ = t % Cfg::UW, hf_ = (t / Cfg::UW) % Cfg::HALVES, sl_ = t / (Cfg::UW * Cfg::HALVES);
+    Slice r;
+    r.writer = sl_ == 0 && ul_ < n_units_valid;
+    r.dst = a.partial + ((int64_t)range * a.q_len + b) * C + (int64_t)(u0 + ul_) * CH + hf_ * CHL;
+    r.sacc = reinterpret_cast<long long *>(smem + Cfg::SP_P_B) + ul_ * CH + hf_ * CHL;
+    return r;
+  };
   if (sparse_first) {
+    const Slice sc = slice_of();
+    const bool writer = sc.writer;
+    float *dst = sc.dst;
+    long long *sacc_w = sc.sacc;
+    // phase first: its sums wait in this workgroup's slab (global memory; the registers are needed by the loop) and are
+    // picked up again by the same lanes at the end
+    if (writer) {
+#pragma unroll
+      for (int i = 0; i < CHL; i++) sacc_w[i] = 0;
+    }
+    __syncthreads();
     sparse_phase();
+    if (writer) {
+#pragma unroll
+      for (int i = 0; i < CHL; i += 4) {
+        float4 v;
+        v.x = (float)((double)sacc_w[i] * (1.0 / 4294967296.0));
+        v.y = (float)((double)sacc_w[i + 1] * (1.0 / 4294967296.0));
+        v.z = (float)((double)sacc_w[i + 2] * (1.0 / 4294967296.0));
+        v.w = (float)((double)sacc_w[i + 3] * (1.0 / 4294967296.0));
+        *reinterpret_cast<float4 *>(dst + i) = v;
+      }
+    }
     __syncthreads();                      // the phase is done with the LDS: the first chunk may land
+    // (the per-lane DMA constants are computed again here: their first definitions are then dead on this path and do
+    //  not occupy registers during the phase)
+    dl = make_dma_lane<BITS>();
+    asm volatile("" : "+v"(dl.tile_row), "+v"(dl.tile_q4), "+v"(dl.lut_tok), "+v"(dl.lut_sub), "+v"(dl.p_head), "+v"(dl.p_tok));
+    df = make_dma_fast<BITS>(a, dl);
     issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
   }
-  constexpr int CHL = Cfg::CHL;
   float acc[CHL];
 #pragma unroll
   for (int i = 0; i < CHL; i++) acc[i] = 0.f;
@@ -1049,9 +1097,15 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #pragma unroll
   for (int i = 0; i < CHL; i++) red[(i * Cfg::SLOTS + sl) * (Cfg::UW * Cfg::HALVES) + lu] = acc[i];
   __syncthreads();
-  if (sl == 0 && ul < n_units_valid) {
-    float *dst = a.partial + ((int64_t)range * a.q_len + b) * C + (int64_t)(u0 + ul) * CH + hf * CHL;
-    float o[CHL];
+  static_assert(Cfg::RED_B <= Cfg::SP_P_B, "the slot sums are read while the outlier accumulators are zeroed");
+  const Slice sc_end = slice_of();
+  const bool writer = sc_end.writer;
+  float *dst = sc_end.dst;
+  long long *sacc_w = sc_end.sacc;
+  float o[CHL];
+#pragma unroll
+  for (int i = 0; i < CHL; i++) o[i] = 0.f;
+  if (writer) {
 #pragma unroll
     for (int i = 0; i < CHL; i++) {
       float s = red[(i * Cfg::SLOTS) * (Cfg::UW * Cfg::HALVES) + lu];
@@ -1059,20 +1113,64 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       for (int k = 1; k < Cfg::SLOTS; k++) s += red[(i * Cfg::SLOTS + k) * (Cfg::UW * Cfg::HALVES) + lu];
       o[i] = s;
     }
+    if (sparse && !sparse_first) {
 #pragma unroll
-    for (int i = 0; i < CHL; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+      for (int i = 0; i < CHL; i++) sacc_w[i] = 0;     // (the writers cover exactly the group's channels)
+    }
   }
 #if KVQ_TRACE
   {
     unsigned long long tt;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
-    tr_acc[5] += (unsigned)tt - tr_prev;   // slot reduce + partial store
+    tr_acc[5] += (unsigned)tt - tr_prev;   // slot reduce
     tr_prev = (unsigned)tt;
   }
 #endif
-  if (sparse && !sparse_first) {
-    __syncthreads();   // the slot reduction is done with the LDS
-    sparse_phase();
+  // dense sums (fp32, exact for a channel without entries) + outlier sums (exact in fixed point, rounded once)
+  if (sparse_first) {
+    if (writer) {
+      // what this lane stored before the loop: asm loads, so that hipcc cannot forward the stored values through
+      // registers (which would keep them live across the loop)
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      f32x4_t q[CHL / 4];
+#pragma unroll
+      for (int i = 0; i < CHL; i += 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[i / 4]) : "v"(dst + i) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < CHL; i += 4) {
+        asm volatile("" : "+v"(q[i / 4]));
+        o[i] += q[i / 4].x; o[i + 1] += q[i / 4].y; o[i + 2] += q[i / 4].z; o[i + 3] += q[i / 4].w;
+      }
+    }
+  } else if (sparse) {
+    // (the dense sums wait in the slab during the phase, like the outlier sums of the other order during the loop)
+    if (writer) {
+#pragma unroll
+      for (int i = 0; i < CHL; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+    }
+    __syncthreads();   // the slot sums are read, the accumulators zeroed: the stage may be overwritten
+    sparse_phase();    // (ends with a barrier: the sums are complete)
+    const Slice sc2 = slice_of();
+    if (sc2.writer) {
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      f32x4_t q[CHL / 4];
+#pragma unroll
+      for (int i = 0; i < CHL; i += 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[i / 4]) : "v"(sc2.dst + i) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < CHL; i += 4) {
+        asm volatile("" : "+v"(q[i / 4]));
+        const float4 v = make_float4(q[i / 4].x + (float)((double)sc2.sacc[i] * (1.0 / 4294967296.0)),
+                                     q[i / 4].y + (float)((double)sc2.sacc[i + 1] * (1.0 / 4294967296.0)),
+                                     q[i / 4].z + (float)((double)sc2.sacc[i + 2] * (1.0 / 4294967296.0)),
+                                     q[i / 4].w + (float)((double)sc2.sacc[i + 3] * (1.0 / 4294967296.0)));
+        *reinterpret_cast<float4 *>(sc2.dst + i) = v;
+      }
+    }
+  }
+  if (writer && (sparse_first || !sparse)) {
+#pragma unroll
+    for (int i = 0; i < CHL; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
   }
 #if KVQ_TRACE
   {
@@ -1206,7 +1304,7 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   pl.tr = tr;
   pl.n_ranges = (int)((L + tr - 1) / tr);
   if (pl.n_ranges < 1) pl.n_ranges = 1;
-  pl.bytes = ((size_t)pl.n_ranges * q_len + (size_t)pl.n_ranges * pl.groups) * H * kHeadDim * sizeof(float) +
+  pl.bytes = (size_t)pl.n_ranges * q_len * H * kHeadDim * sizeof(float) +
              (size_t)H * 2 * sizeof(float);   // + the (max, normaliser) pairs of the fused softmax
   return pl;
 }
@@ -1230,7 +1328,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   a.tr = pl.tr;
   a.groups = pl.groups;
   a.n_units = pl.n_units;
-  a.sparse_partial = a.partial + (size_t)pl.n_ranges * a.q_len * a.H * kHeadDim;
+  a.sparse_partial = nullptr;   // (the outlier sums are part of the dense partials)
   dim3 grid(pl.n_ranges * pl.groups, 1, a.q_len), block(Cfg::NT);
   if (fs) {
     a.scores = fs->scores;
@@ -1245,7 +1343,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
     if (fs->v_sink != nullptr) accumulate = 1;     // the reduce adds the slabs onto the sink tokens' output
     a.mz = nullptr;
     if (fs->n_parts > kMergeInKernelParts) {
-      float *mz = a.sparse_partial + (size_t)pl.n_ranges * pl.groups * a.H * kHeadDim;   // (tail of the workspace)
+      float *mz = a.partial + (size_t)pl.n_ranges * a.q_len * a.H * kHeadDim;   // (tail of the workspace)
       softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz,
                                                 fs->v_sink, mul);
       int rc0 = check_launch();
@@ -1260,8 +1358,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   if (rc) return rc;
   const int C = a.H * kHeadDim;
   dim3 rgrid((C + 15) / 16, a.q_len);
-  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, a.sparse_partial, mul, pl.n_ranges,
-                                             a.idx ? pl.n_ranges * pl.groups : 0, a.q_len, C, accumulate);
+  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, nullptr, mul, pl.n_ranges, 0, a.q_len, C, accumulate);
   return check_launch();
 }
 
