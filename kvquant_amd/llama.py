@@ -288,12 +288,31 @@ def get_loaders(name, nsamples=128, seed=0, seqlen=2048, model="", vocab_size=32
 
 
 @torch.no_grad()
-def generate(model, input_ids, max_length=None, max_new_tokens=None, eos_token_id=None, pad_token_id=None):
-    """Greedy decoding with the compressed cache: the reference's `model.generate(..., kvquant=True)`
+def _warp_logits(logits, temperature, top_k, top_p):
+    """HF's sampling warpers in their order (TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)"""
+    if temperature is not None and temperature != 1.0:
+        logits = logits / temperature
+    if top_k is not None and 0 < top_k < logits.shape[-1]:
+        kth = torch.topk(logits, top_k, dim=-1).values[..., -1, None]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        srt, idx = torch.sort(logits, descending=False, dim=-1)
+        cum = srt.softmax(dim=-1).cumsum(dim=-1)
+        drop = cum <= (1 - top_p)
+        drop[..., -1:] = False                                  # (min_tokens_to_keep = 1)
+        logits = logits.masked_fill(drop.scatter(-1, idx, drop), float("-inf"))
+    return logits
+
+
+def generate(model, input_ids, max_length=None, max_new_tokens=None, eos_token_id=None, pad_token_id=None,
+             do_sample=False, temperature=1.0, top_k=50, top_p=1.0, min_length=0, generator=None):
+    """Decoding with the compressed cache: the reference's `model.generate(..., kvquant=True)`
     (generation/utils.py:2325-2416) -- the prompt goes through the model once (parallel pack of its K / V), then every
     step feeds ONLY the newest token (`input_ids = next_tokens[:, None]`, :2378-2380), the returned sequence is the
     prompt with the generated tokens appended, and the loop stops at `max_length` positions (:2401-2406) or once EOS
-    has been produced.  Batch 1."""
+    has been produced.  Greedy by default; `do_sample=True` is what lwm/llama_inference.py:124-131 asks for
+    (multinomial sampling after HF's default warpers: temperature 1, top-k 50; `min_length` suppresses EOS until the
+    sequence is that long).  Batch 1."""
     if input_ids.shape[0] != 1:
         raise ValueError("the compressed-cache path is batch 1 (ML:1408)")
     dev = model.gpus[0] if hasattr(model, "gpus") else next(model.parameters()).device
@@ -311,7 +330,14 @@ def generate(model, input_ids, max_length=None, max_new_tokens=None, eos_token_i
     pos = n_prompt - 1                   # position of the last token fed so far
     while True:
         out = model(cur, use_cache=False)
-        nxt = torch.argmax(out.logits[:, -1, :], dim=-1)
+        logits = out.logits[:, -1, :].float()
+        if eos_token_id is not None and seq.shape[1] < min_length:
+            logits[:, eos_token_id] = float("-inf")             # MinLengthLogitsProcessor
+        if do_sample:
+            probs = _warp_logits(logits, temperature, top_k, top_p).softmax(dim=-1)
+            nxt = torch.multinomial(probs, num_samples=1, generator=generator).squeeze(1)
+        else:
+            nxt = torch.argmax(logits, dim=-1)
         if eos_token_id is not None and not unfinished:
             nxt = torch.full_like(nxt, pad_token_id)
         seq = torch.cat((seq, nxt[:, None]), dim=-1)
@@ -322,6 +348,82 @@ def generate(model, input_ids, max_length=None, max_new_tokens=None, eos_token_i
         if not unfinished or seq.shape[1] >= max_length or max_length <= pos + 1:
             break
     return seq
+
+
+def inference_main(argv=None):
+    """lwm/llama_inference.py:39-138 (the same arguments): load a long-context Llama with the compressed cache sized by
+    --maxseqlen, read the quantizer pickle, sample a continuation of --text and print it with the wall time.
+    Extras for boxes without a tokenizer: --token-ids "1,2,3" instead of --text (the ids are printed back), --seed."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m kvquant_amd.llama inference")
+    ap.add_argument("model", type=str, help="llama model to load")
+    ap.add_argument("--abits", type=int, default=16, choices=[2, 3, 4, 16],
+                    help="#bits to use for quantization; use 16 for evaluating base model.")
+    ap.add_argument("--text", type=str, help="input text")
+    ap.add_argument("--token-ids", type=str, default=None, help="(extra) comma-separated prompt token ids instead of --text")
+    ap.add_argument("--min_length", type=int, default=10, help="The minimum length of the sequence to be generated.")
+    ap.add_argument("--max_length", type=int, default=256, help="The maximum length of the sequence to be generated.")
+    ap.add_argument("--maxseqlen", type=int, default=-1, help="Used to set KV cache size")
+    ap.add_argument("--quantizer-path", type=str, help="Path to quantizers.")
+    ap.add_argument("--include_sparse", action="store_true", help="Whether to use dense-and-sparse quantization.")
+    ap.add_argument("--sparsity-threshold", type=float, default=1, help="Outlier percentile.")
+    ap.add_argument("--first_few_fp16", type=int, default=0, help="Store first few tokens separately in fp16")
+    ap.add_argument("--norm", action="store_true", help="Whether to use q-norm.")
+    ap.add_argument("--seed", type=int, default=None, help="(extra) seed of the sampler")
+    ap.add_argument("--greedy", action="store_true", help="(extra) arg-max decoding instead of sampling")
+    args = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("kvquant_amd.llama needs a GPU (no CPU fallback)")
+    if args.abits != 16 and args.maxseqlen <= 0:
+        raise SystemExit("--maxseqlen must be set: it sizes the preallocated compressed cache")
+    if (args.text is None) == (args.token_ids is None):
+        raise SystemExit("give the prompt as --text or as --token-ids")
+    dev = torch.device("cuda:0")
+    model = get_model(args.model, 2048, args.maxseqlen, args.abits if args.abits != 16 else 4, args.include_sparse,
+                      args.first_few_fp16)
+    model.eval()
+    model = model.half()
+    tokenizer = None
+    if args.text is not None:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(args.model, use_fast=False)
+        input_ids = tokenizer.encode(args.text, return_tensors="pt")
+    else:
+        input_ids = torch.tensor([[int(t) for t in args.token_ids.split(",")]], dtype=torch.long)
+    eos = getattr(model.config, "eos_token_id", None)
+    pad = getattr(model.config, "pad_token_id", None)
+    if eos is not None and pad is None:
+        pad = eos if not isinstance(eos, (list, tuple)) else eos[0]
+    gen = None
+    if args.seed is not None:
+        gen = torch.Generator(device=dev).manual_seed(args.seed)
+    if args.abits != 16:
+        set_devices(model)
+        patch_llama(model, sparsity_threshold=args.sparsity_threshold)
+        print("Load quantizers.")
+        load_quantizers(model, args.quantizer_path, args.include_sparse, args.sparsity_threshold, args.norm)
+        t1 = time.time()
+        with torch.no_grad():
+            ids = generate(model, input_ids, max_length=args.max_length, min_length=args.min_length, eos_token_id=eos,
+                           pad_token_id=pad, do_sample=not args.greedy, generator=gen)
+        torch.cuda.synchronize()
+        t2 = time.time()
+    else:
+        model.to(dev)
+        if args.seed is not None:
+            torch.manual_seed(args.seed)
+        t1 = time.time()
+        with torch.no_grad():
+            ids = model.generate(input_ids.to(dev), do_sample=not args.greedy, min_length=args.min_length,
+                                 max_length=args.max_length, use_cache=True, pad_token_id=pad)
+        torch.cuda.synchronize()
+        t2 = time.time()
+    if tokenizer is not None:
+        print(tokenizer.decode([el.item() for el in ids[0]]))
+    else:
+        print("token ids:", ids[0].tolist())
+    print("Time: ", t2 - t1)
+    return 0
 
 
 def main(argv=None):
@@ -417,4 +519,7 @@ def benchmark_fp16(model, input_ids, check=False, verbose=False):
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "inference":        # lwm/llama_inference.py
+        raise SystemExit(inference_main(sys.argv[2:]))
     raise SystemExit(main())

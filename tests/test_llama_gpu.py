@@ -138,6 +138,22 @@ def test_command_line_driver_and_generate(gpu, tmp_path, capsys):
     assert m2.model.layers[0].self_attn.kcache.klen == 17      # the last generated token was never fed back
     seq2 = kl.generate(_fresh(kl, mdir, qpath, gpu), prompt, max_length=15)
     assert seq2.shape == (1, 15) and torch.equal(seq2, seq[:, :15])
+    # sampling (lwm/llama_inference.py:124-131): top_k = 1 is the greedy path; a seeded sampler is reproducible
+    seq3 = kl.generate(_fresh(kl, mdir, qpath, gpu), prompt, max_new_tokens=6, do_sample=True, top_k=1)
+    assert torch.equal(seq3, seq)
+    gs = [torch.Generator(device=gpu).manual_seed(11) for _ in range(2)]
+    sa = kl.generate(_fresh(kl, mdir, qpath, gpu), prompt, max_new_tokens=8, do_sample=True, temperature=0.7, top_p=0.9, generator=gs[0])
+    sb = kl.generate(_fresh(kl, mdir, qpath, gpu), prompt, max_new_tokens=8, do_sample=True, temperature=0.7, top_p=0.9, generator=gs[1])
+    assert sa.shape == (1, 20) and torch.equal(sa, sb)
+    # the long-context inference driver (lwm/llama_inference.py), prompt given as token ids (no tokenizer offline)
+    rc = kl.inference_main([str(mdir), "--abits", "4", "--include_sparse", "--sparsity-threshold", "0.99",
+                            "--first_few_fp16", "1", "--maxseqlen", "128", "--quantizer-path", str(qpath),
+                            "--token-ids", ",".join(str(int(t)) for t in prompt[0]), "--min_length", "14",
+                            "--max_length", "20", "--seed", "5"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Load quantizers." in out and "Time:" in out
+    ids = [int(t) for t in out.split("token ids: [")[1].split("]")[0].split(",")]
+    assert ids[:12] == prompt[0].tolist() and 14 <= len(ids) <= 20
 
 
 def _fresh(kl, mdir, qpath, gpu):
