@@ -62,6 +62,8 @@ def parse():
                          "stream whose context is split along the token axis (strong scaling, one all-gather per layer)")
     ap.add_argument("--sweep", action="store_true", help="every BASELINE configuration, one JSON line each (1 GPU)")
     ap.add_argument("--retrieval", action="store_true", help="plant a retrievable token and check it (config 5 proxy)")
+    ap.add_argument("--time-every", type=int, default=11,
+                    help="bracket every N-th layer's two matvec launches with HIP events (1 = all; the events cost time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp16-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=8192)
@@ -154,9 +156,11 @@ class KernelTimers:
     (kvq_decode_step_events: before / after the q.K^T launch, before / after the p.V kernel + slab reduce), created
     and read here through the HIP runtime."""
 
-    def __init__(self):
+    def __init__(self, every=1):
         import ctypes
         self.ct = ctypes
+        self.every = every            # time every N-th layer call (N = 3 walks through all layers of a 32-layer stack)
+        self.calls = 0
         self.hip = ctypes.CDLL("libamdhip64.so")
         self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
@@ -184,9 +188,13 @@ class KernelTimers:
         me = self
 
         def timed(layer, *a, **kw):
-            q = me._quad()
-            lib.kvq_decode_step_events(q)
-            me.quads.append(q)
+            # every `self.every`-th decode_step call is bracketed (4 event records on the launch stream are not free:
+            # all 32 layers of a step timed cost 0.1 - 0.4 ms per step)
+            me.calls += 1
+            if me.every and me.calls % me.every == 0:
+                q = me._quad()
+                lib.kvq_decode_step_events(q)
+                me.quads.append(q)
             return me._orig(layer, *a, **kw)
         ops.decode_step = timed
 
@@ -540,7 +548,7 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
     template = torch.zeros(1, 1, C, dtype=torch.float16, device=dev)
     x_in = torch.zeros(1, 1, C, dtype=torch.float16, device=dev)
     pipe = sharding.StreamPipeline(stage, streams, rank=rank, world=world if sharded else 1)
-    timers = KernelTimers()
+    timers = KernelTimers(every=max(1, args.time_every))
     timers.install()
     pipe.run(args.warmup, lambda s, st: x_in, template, step0=0)
     timers.reset()
@@ -614,7 +622,10 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
-                         "bytes_per_token": per_tok},
+                         "bytes_per_token": per_tok,
+                         "timed_launches": len(timers.quads) or len(timers.pairs[dom]),
+                         "timing": "HIP events on the launch stream around every %d-th layer's launch inside the timed region"
+                                   % max(args.time_every, 1)},
             "kernels": {"score_k_us": k_us, "mix_v_us": v_us,
                         "score_k_GBps": kb / (k_us * 1e-6) / 1e9 if k_us else None,
                         "mix_v_GBps": vb / (v_us * 1e-6) / 1e9 if v_us else None,

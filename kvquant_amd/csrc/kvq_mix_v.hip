@@ -1309,7 +1309,7 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   return pl;
 }
 
-constexpr int kMergeInKernelParts = 128;   // up to 32K cached tokens: the p.V workgroups merge the softmax partials themselves
+constexpr int kMergeInKernelParts = 256;   // up to 64K cached tokens: the p.V workgroups merge the softmax partials themselves
 
 struct FusedSoftmax {
   const float *scores, *parts;

@@ -986,16 +986,24 @@ static int workgroup_slots(K kernel, int threads, int fallback_per_cu) {
   return cu_count() * per_cu;
 }
 
-// Head groups per full tile.  A workgroup of hpg heads costs ~(hpg + 2) units (2 = the tile's trig, prologue
-// and epilogue); workgroups run in ceil(n / slots) rounds.  Pick the divisor of H with the cheapest
-// makespan; ties go to the larger group (better trig amortisation).
+// Head groups per full tile.  A workgroup of hpg heads costs ~(hpg + 3.2) units with two workgroups per CU: a head
+// iteration is 2.3 us, the tile's trig + prologue + epilogue 7.3 us (profiles/r03_a_traces.txt); alone on its CU it takes
+// 3/4 of that.  `slots` workgroups run side by side; full generations cost a workgroup each, the last partial one
+// between 3/4 (every CU holds at most one) and a whole workgroup, and every generation ~1.5 units of ramp.
+// Fitted to the launch times of 2K ... 256K caches (profiles/r03_b_planner.txt); the round-counting model it replaces
+// cut a 96K cache into 1536 workgroups of 8 heads (97 us, now 80) and ran 160K as two rounds of 32 heads (162 us, now
+// 131).  Pick the divisor of H with the shortest makespan; ties go to the larger group (better trig amortisation).
 static int pick_groups(int H, int64_t tiles, int q_len, int max_hpg, int slots) {
   int best = H;
   double best_cost = 1e30;
   for (int d = 1; d <= H; d++) {
     if (H % d || H / d > max_hpg) continue;
     const int64_t n = tiles * d * q_len;
-    const double cost = (double)((n + slots - 1) / slots) * (H / d + 2);
+    const double wg = H / d + 3.2;
+    const int64_t full = n / slots, r = n % slots;
+    // (partial generation: 3/4 of a workgroup while no CU holds two of them, rising to a whole one as the CUs fill up)
+    const double part = 2 * r <= slots ? 0.75 : 0.75 + 0.25 * (double)(2 * r - slots) / slots;
+    const double cost = (double)full * wg + (r ? wg * part : 0.0) + 1.5 * (double)(full + (r ? 1 : 0));
     if (cost < best_cost - 1e-9) {
       best_cost = cost;
       best = d;
