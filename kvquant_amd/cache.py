@@ -545,17 +545,18 @@ class QuantV(nn.Module):
 
 ONE_CALL_PER_LAYER = os.environ.get("KVQ_DECODE_MULTICALL", "0") != "1"   # (env: A/B runs against the five-call path)
 FUSE_SOFTMAX_INTO_MIX_V = False
-# ... except for short caches, where a launch less is worth more than the second conversion (env: A/B runs)
-FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", "32768"))
+# The p.V kernel normalises the raw scores itself (kvq_mix_v_softmax: one launch and one pass over the probabilities
+# less).  Round 2 this lost beyond 32K tokens -- every probability was converted twice, by the workgroup that streams its
+# head's rows and by the one that owned its token's outliers for ALL heads; since a workgroup takes the outliers of its
+# own heads only, it wins at every length (profiles/r03_b_fused_softmax.txt: 128K 6.12 -> 5.98 ms/step).  Env: A/B runs.
+FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", str(1 << 62)))
 
 
 def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
     """One decode token through a layer's compressed KV path, GPU-resident, 5 launches:
     prologue (K append | V append | K tables) -> q.K^T (+ first softmax pass) -> softmax finish -> p.V -> slab
-    reduce; 4 launches up to FUSE_SOFTMAX_UP_TO cached tokens, where the p.V kernel normalises the raw scores
-    itself (kvq_mix_v_softmax: 4K contexts 3.04 -> 2.65 ms per 32-layer step).  For long caches that fusion is
-    SLOWER (FUSE_SOFTMAX_INTO_MIX_V: 93 vs 88 us at 128K for the pair of launches, because every probability is then
-    evaluated twice: by the workgroup that streams its head's rows and by the one that owns its token's outliers).
+    reduce; by default 4 launches (+ a 4 us merge of the softmax partials beyond 64K tokens): the p.V kernel normalises
+    the raw scores itself (kvq_mix_v_softmax, FUSE_SOFTMAX_UP_TO above).
     q: [H, hd] RoPE'd query, k, v: [C] pre-RoPE key / value, all fp16 or all fp32 (no conversion
     launches).  sink_scores: optional f16 [H, n_sink] already scaled scores of the fp16 sink tokens.
     k_sink (f16 [H, 128, n_sink], post-RoPE) / v_sink (f16 [H, n_sink, 128]) instead: the fp16 sink caches themselves --

@@ -9,6 +9,9 @@
 
 #include "../../include/kvq.h"
 
+// measurement hook of kvq_decode_step (kvq_decode_step.hip): the fused p.V route calls it in front of its p.V kernel
+extern "C" void kvq_step_mark_pv(hipStream_t st);
+
 namespace kvq {
 
 // half(half(raw) * inv): the reference casts the scores to fp16 and divides that tensor by a Python scalar

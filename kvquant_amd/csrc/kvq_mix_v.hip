@@ -1350,6 +1350,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
       if (rc0) return rc0;
       a.mz = mz;
     }
+    kvq_step_mark_pv(st);      // (measurement hook of kvq_decode_step: the p.V kernel starts here)
     mix_v_kernel<BITS, true><<<grid, block, 0, st>>>(a);
   } else {
     mix_v_kernel<BITS, false><<<grid, block, 0, st>>>(a);
