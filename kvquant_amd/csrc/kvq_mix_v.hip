@@ -53,6 +53,9 @@
 #ifndef KVQ_V_WAVES
 #define KVQ_V_WAVES 4    // waves per SIMD the register allocation aims at
 #endif
+#ifndef KVQ_V_MERGE_PARTS
+#define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles the p.V workgroups merge the softmax partials themselves
+#endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24
 #endif
@@ -1309,7 +1312,7 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   return pl;
 }
 
-constexpr int kMergeInKernelParts = 256;   // up to 64K cached tokens: the p.V workgroups merge the softmax partials themselves
+constexpr int kMergeInKernelParts = KVQ_V_MERGE_PARTS;   // up to this many score tiles (256 tokens each): the p.V workgroups merge the softmax partials themselves
 
 struct FusedSoftmax {
   const float *scores, *parts;
