@@ -674,6 +674,11 @@ def main():
         if world == 1:
             raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE=1" % args.gpus)
         args.gpus = world
+    # development (a box with ONE GPU): KVQ_BENCH_ONE_GPU=1 puts every rank on cuda:0 and moves the hand-overs over gloo
+    # (RCCL refuses two ranks on one device) -- the multi-rank code paths of this file, not a measurement
+    one_gpu = os.environ.get("KVQ_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     if torch.cuda.device_count() <= local:
         raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
@@ -681,7 +686,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     from kvquant_amd import _lib
     if os.environ.get("KVQ_LIB"):      # development: time an alternative build of the library (tools/abl)
         _lib.LIB_PATH = os.path.abspath(os.environ["KVQ_LIB"])

@@ -99,7 +99,7 @@ def _stream_worker(rank, world, port, n_layers, streams, steps, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_layers,streams", [(2, 6, 2), (3, 7, 3), (3, 6, 1), (2, 4, 5)])
+@pytest.mark.parametrize("world,n_layers,streams", [(2, 6, 2), (3, 7, 3), (3, 6, 1), (2, 4, 5), (4, 8, 4), (8, 32, 8)])
 def test_stream_pipeline_over_gloo(world, n_layers, streams):
     """real layer outputs (stateful, order-sensitive) move through the stages; every stream's result equals the
     single-process evaluation and every rank ran every (step, stream) item exactly once, in order"""
