@@ -345,7 +345,8 @@ KVQ_API int kvq_decode_step(const kvq_layer *layer, int64_t kcol, int64_t vcol, 
                     uint16_t *sink_probs, float *out, int fuse_softmax, void *workspace, size_t workspace_bytes,
                     void *stream);
 /* measurement hook: events4 = four hipEvent_t (or NULL entries) recorded on the stream before / after the q.K^T launch
- * and before / after the p.V launches (p.V kernel + slab reduce; with fuse_softmax the merged kernel) of the NEXT
+ * and before / after the p.V launches (p.V kernel + slab reduce; with fuse_softmax: from the fused kernel's launch, i.e.
+ * behind the small merge of the softmax partials that long caches need) of the NEXT
  * kvq_decode_step on this thread; the hook clears itself after that call.  NULL: no events. */
 KVQ_API int kvq_decode_step_events(void *const *events4);
 /* the same for a stack of layers that follow each other without other work in between (all at the same column;
