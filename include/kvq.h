@@ -266,6 +266,12 @@ KVQ_API int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const
  * entries: coalesced loads, no segmented scan (the reference layout costs +23 us at
  * 128K for exactly that). */
 KVQ_API int kvq_score_k_softmax_parts(int bits, int64_t L, int sparse);
+/* Host logic of the score launches (no device work; exported for tests and capacity planning): into how many head
+ * groups the launch cuts each full token tile, given `tiles` full tiles, q_len query rows, the kernel's limit on
+ * heads per workgroup and `slots` = workgroups the GPU holds at once (512 on MI355X for the 256-token kernel).  The
+ * reference launches one block per (128 tokens, head) whatever the size (KCU:3437-3488); here the grid is planned with
+ * a makespan model (kvq_score_k.hip, pick_groups).  0 = invalid arguments. */
+KVQ_API int kvq_score_k_head_groups(int H, int64_t tiles, int q_len, int max_heads_per_group, int slots);
 KVQ_API int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul,
                          const float *lut, int H, int hd, int64_t L, int64_t max_len,
                          float rope_theta, int pos_offset, const float *outliers,

@@ -71,6 +71,7 @@ SIGNATURES = {
                                  _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vn, _sk, _vp, _sz, _vp]),
     "kvq_score_k_prepared": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_score_k_softmax_parts": (_i, [_i, _i64, _i]),
+    "kvq_score_k_head_groups": (_i, [_i, _i64, _i, _i, _i]),
     "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                           _sz, _f, _vp, _i, _vp]),
     "kvq_softmax_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp]),

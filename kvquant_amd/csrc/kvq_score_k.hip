@@ -1080,6 +1080,11 @@ using namespace kvq;
 
 extern "C" {
 
+int kvq_score_k_head_groups(int H, int64_t tiles, int q_len, int max_heads_per_group, int slots) {
+  if (H <= 0 || tiles <= 0 || q_len <= 0 || max_heads_per_group <= 0 || slots <= 0) return 0;
+  return pick_groups(H, tiles, q_len, max_heads_per_group, slots);
+}
+
 size_t kvq_score_k_workspace_bytes(int bits, int q_len, int H) {
   if (bits < 2 || bits > 4 || q_len <= 0 || H <= 0) return 0;
   return (size_t)q_len * H * (tab_bytes(bits) + kHeadDim * sizeof(float));

@@ -46,6 +46,23 @@ def test_version_and_errors(lib):
     assert lib.kvq_score_k_workspace_bytes(4, 1, 32) == 32 * (16384 + 128 * 4)   # tables + fp32 copy of q
 
 
+def test_score_launch_planner(lib):
+    """host logic of the score launches (kvq_score_k_head_groups): the head groups per token tile for LLaMA-2-7B's 32
+    heads on 512 workgroup slots -- the choices measured in profiles/r03_b_planner.txt"""
+    g = lambda tiles, H=32, q_len=1, mx=32, slots=512: lib.kvq_score_k_head_groups(H, tiles, q_len, mx, slots)  # noqa: E731
+    assert g(512) == 1            # 128K: one workgroup per tile, all 32 heads, the chip exactly full
+    assert g(1024) == 1           # 256K: two full generations of them
+    assert g(384) == 1            # 96K: a partial generation of whole tiles (round counting cut it into 1536 pieces)
+    assert g(640) == 2            # 160K: 1280 half-tile workgroups instead of two rounds of 32 heads
+    assert g(128) == 4            # 32K: four groups of 8 heads fill the chip
+    assert g(64) == 8
+    for tiles in (1, 3, 17, 100, 513, 4096, 40000):
+        for H, mx in ((32, 32), (40, 32), (8, 8), (128, 32)):
+            d = g(tiles, H=H, mx=mx)
+            assert d >= 1 and H % d == 0 and H // d <= mx, (tiles, H, d)
+    assert g(0) == 0 and g(512, H=0) == 0 and g(512, slots=0) == 0     # invalid arguments
+
+
 def test_legacy_module_surface():
     from kvquant_amd import quant_cuda
     from oracle import quant_cuda_ref
