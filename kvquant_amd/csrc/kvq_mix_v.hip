@@ -54,7 +54,7 @@
 #define KVQ_V_WAVES 4    // waves per SIMD the register allocation aims at
 #endif
 #ifndef KVQ_V_MERGE_PARTS
-#define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles the p.V workgroups merge the softmax partials themselves
+#define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles (64K tokens) the p.V workgroups merge the softmax partials themselves (beyond: 6.09 vs 6.01 ms/step at 128K)
 #endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24
@@ -504,30 +504,46 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
         mzw[h] = make_float2(t.x, 1.0f / t.y);     // (max, 1 / normaliser)
       }
     } else {
-      // few partials: 16 lanes per head merge them (+ the fp16 sink scores) here, the same way in every workgroup
-      const int sub = tid & 15;
-      for (int hb = 0; hb < a.H; hb += Cfg::NT / 16) {
-        const int h = hb + (tid >> 4);
-        const bool hv = h < a.H;
-        const float2 *pr = reinterpret_cast<const float2 *>(a.parts) + (int64_t)(hv ? h : 0) * a.n_parts;
+      // The workgroup merges the partials of the heads it needs itself (+ the fp16 sink scores), the same way in every
+      // workgroup: its own unit group's heads -- 32 lanes per head -- or, for the workgroup that writes the sink
+      // probabilities, all of them.  The partials are read 16 per lane at a time, all loads of a batch in flight together
+      // (one load per merge step made this 11 us per workgroup at 128K).
+      const bool all_heads = blockIdx.x == 0 && a.n_sink > 0;
+      const int hfirst = all_heads ? 0 : h0;
+      int hcount = all_heads ? a.H : (n_units_valid + Cfg::UPH - 1) / Cfg::UPH;
+      if (hfirst + hcount > a.H) hcount = a.H - hfirst;
+      constexpr int LPH = 32;                                     // lanes per head: the same partition in every workgroup
+      const int sub = tid & (LPH - 1);
+      constexpr int MB = 16;                                      // partials per lane and batch
+      for (int hb = 0; hb < hcount; hb += Cfg::NT / LPH) {
+        const int hr = hb + tid / LPH;
+        const bool hv = hr < hcount;
+        const int h = hfirst + (hv ? hr : 0);
+        const float2 *pr = reinterpret_cast<const float2 *>(a.parts) + (int64_t)h * a.n_parts;
         float M = -INFINITY, Z = 0.f;
-        for (int i = sub; i < a.n_parts; i += 16) {
-          const float2 ms = hv ? pr[i] : make_float2(-INFINITY, 0.f);
-          if (ms.x > -INFINITY) {
-            const float mn = fmaxf(M, ms.x);
-            Z = Z * mz_w(M - mn) + ms.y * mz_w(ms.x - mn);
-            M = mn;
+        for (int i0 = sub; i0 < a.n_parts; i0 += LPH * MB) {
+          float2 ms[MB];
+#pragma unroll
+          for (int k = 0; k < MB; k++) {
+            const int i = i0 + LPH * k;
+            ms[k] = (hv && i < a.n_parts) ? pr[i] : make_float2(-INFINITY, 0.f);
           }
+#pragma unroll
+          for (int k = 0; k < MB; k++)
+            if (ms[k].x > -INFINITY) {
+              const float mn = fmaxf(M, ms[k].x);
+              Z = Z * mz_w(M - mn) + ms[k].y * mz_w(ms[k].x - mn);
+              M = mn;
+            }
         }
         if (hv)
-          for (int i = sub; i < a.n_sink; i += 16) {
+          for (int i = sub; i < a.n_sink; i += LPH) {
             const float x = __half2float(a.sink[h * a.n_sink + i]);
             const float mn = fmaxf(M, x);
             Z = Z * expf(M - mn) + expf(x - mn);
             M = mn;
           }
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) {
+        for (int d = LPH / 2; d >= 1; d >>= 1) {
           const float mo = __shfl_xor(M, d), zo = __shfl_xor(Z, d);
           const float mn = fmaxf(M, mo);
           Z = (mn == -INFINITY) ? 0.f : Z * mz_w(M - mn) + zo * mz_w(mo - mn);
