@@ -159,8 +159,9 @@ class KernelTimers:
     def __init__(self, every=1):
         import ctypes
         self.ct = ctypes
-        self.every = every            # time every N-th layer call (N = 3 walks through all layers of a 32-layer stack)
+        self.every = every            # time every N-th layer call (N coprime with the layer count walks through all layers)
         self.calls = 0
+        self.first = True
         self.hip = ctypes.CDLL("libamdhip64.so")
         self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
@@ -191,7 +192,8 @@ class KernelTimers:
             # every `self.every`-th decode_step call is bracketed (4 event records on the launch stream are not free:
             # all 32 layers of a step timed cost 0.1 - 0.4 ms per step)
             me.calls += 1
-            if me.every and me.calls % me.every == 0:
+            if me.first or (me.every and me.calls % me.every == 0):      # (at least one sample per timed region)
+                me.first = False
                 q = me._quad()
                 lib.kvq_decode_step_events(q)
                 me.quads.append(q)
@@ -221,6 +223,7 @@ class KernelTimers:
         torch.cuda.synchronize()
         self.pool.extend(self.quads)
         self.quads = []
+        self.first = True
         for k in self.pairs:
             self.pairs[k].clear()
 
