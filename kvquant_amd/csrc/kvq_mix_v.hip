@@ -127,7 +127,6 @@ struct MixArgs {
   const float *outliers;
   const int32_t *idx;
   float *partial;          // [n_ranges][q_len][C]
-  float *sparse_partial;   // [n_ranges*groups][C] (query row 0 only), or unused
   int H;
   int q_len;
   int64_t L;
@@ -1211,10 +1210,9 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 
 // mul[b][c] (+)= sum_r partial[r][b][c], fixed order.  16 channels x 64 slab lanes per block: 256 blocks at C = 4096
 // (one per CU), 64-byte row segments, all of a lane's loads in flight (the pass is bound by memory latency:
-// ~770 slabs at 128K = 12 per lane).
+// 456 slabs at 128K = 8 per lane; the outlier sums are part of the slabs).
 __global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restrict__ partial,
-                                                            const float *__restrict__ sparse_partial,
-                                                            float *__restrict__ mul, int n_ranges, int n_sparse,
+                                                            float *__restrict__ mul, int n_ranges,
                                                             int q_len, int C, int accumulate) {
   __shared__ float red[64][17];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
@@ -1222,7 +1220,7 @@ __global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restr
   const int b = blockIdx.y;
   float s = 0.f;
   if (c < C) {
-    // dense slabs [r][b][c] and (query row 0 only) sparse slabs [k][c], 8 loads in flight per lane and array
+    // slabs [r][b][c], 8 loads in flight per lane
     auto run = [&](const float *src, int64_t stride, int n) {
       int r = rg;
       for (; r + 7 * 64 < n; r += 8 * 64) {
@@ -1239,7 +1237,6 @@ __global__ __launch_bounds__(1024) void mix_v_reduce_kernel(const float *__restr
       for (int k = 0; k < 8; k++) s += v[k];
     };
     run(partial + (int64_t)b * C + c, (int64_t)q_len * C, n_ranges);
-    if (b == 0 && n_sparse > 0) run(sparse_partial + c, C, n_sparse);
   }
   red[rg][cl] = s;
   __syncthreads();
@@ -1347,7 +1344,6 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   a.tr = pl.tr;
   a.groups = pl.groups;
   a.n_units = pl.n_units;
-  a.sparse_partial = nullptr;   // (the outlier sums are part of the dense partials)
   dim3 grid(pl.n_ranges * pl.groups, 1, a.q_len), block(Cfg::NT);
   if (fs) {
     a.scores = fs->scores;
@@ -1378,7 +1374,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   if (rc) return rc;
   const int C = a.H * kHeadDim;
   dim3 rgrid((C + 15) / 16, a.q_len);
-  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, nullptr, mul, pl.n_ranges, 0, a.q_len, C, accumulate);
+  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, mul, pl.n_ranges, a.q_len, C, accumulate);
   return check_launch();
 }
 
@@ -1455,7 +1451,6 @@ static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int
   a.outliers = outliers;
   a.idx = outlier_idx;
   a.partial = reinterpret_cast<float *>(workspace);
-  a.sparse_partial = nullptr;
   a.H = H;
   a.q_len = q_len;
   a.L = L;
