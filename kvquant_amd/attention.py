@@ -51,7 +51,7 @@ class KVQuantAttention(nn.Module):
 
     def __init__(self, hidden_size=4096, num_heads=32, abits=4, include_sparse=True, first_few_fp16=0,
                  maxseqlen=4096, rope_theta=10000.0, sparsity_threshold=0.99, device=None,
-                 dtype=torch.float16, bias=False, make_proj=True, use_orig_sparse=False):
+                 dtype=torch.float16, bias=False, make_proj=True, use_orig_sparse=False, compact=False):
         super().__init__()
         self.hidden_size = hidden_size
         self.num_heads = num_heads
@@ -68,11 +68,11 @@ class KVQuantAttention(nn.Module):
         self.kcache = QuantK(bits=abits, hidden_size=hidden_size, num_heads=num_heads,
                              max_position_embeddings=maxseqlen, include_sparse=include_sparse,
                              sparsity_threshold=sparsity_threshold, rope_theta=rope_theta,
-                             first_few_fp16=first_few_fp16, device=device)
+                             first_few_fp16=first_few_fp16, device=device, compact=compact)
         self.vcache = QuantV(bits=abits, hidden_size=hidden_size, num_heads=num_heads,
                              max_position_embeddings=maxseqlen, include_sparse=include_sparse,
                              sparsity_threshold=sparsity_threshold, first_few_fp16=first_few_fp16,
-                             device=device)
+                             device=device, compact=compact)
         if first_few_fp16 > 0:
             self.kcache_fp16 = torch.zeros((1, num_heads, self.head_dim, first_few_fp16), dtype=dtype,
                                            device=self.kcache.device)

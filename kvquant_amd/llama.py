@@ -70,9 +70,11 @@ def _attn_forward(self, hidden_states, position_embeddings=None, attention_mask=
     return self.o_proj(out.to(hidden_states.dtype)), None
 
 
-def patch_llama(model, sparsity_threshold=0.99):
+def patch_llama(model, sparsity_threshold=0.99, compact=False):
     """give every decoder layer's self_attn the compressed KV path.  `model`: LlamaForCausalLM / LlamaModel whose
-    config carries the KVQuant fields (kvquant_config).  Caches are created on each layer's current device."""
+    config carries the KVQuant fields (kvquant_config).  Caches are created on each layer's current device.
+    compact=True: the opt-in 4-byte outlier entries (fp16 residual + channel; kvquant_amd.cache) -- the
+    GPU-resident paths only, lossy against the reference format by the fp16 rounding of the residuals."""
     cfg = model.config
     kvquant_config(cfg)
     if getattr(cfg, "num_key_value_heads", cfg.num_attention_heads) != cfg.num_attention_heads:
@@ -89,7 +91,7 @@ def patch_llama(model, sparsity_threshold=0.99):
         core = KVQuantAttention(hidden_size=cfg.hidden_size, num_heads=cfg.num_attention_heads, abits=cfg.abits,
                                 include_sparse=cfg.include_sparse, first_few_fp16=cfg.first_few_fp16,
                                 maxseqlen=cfg.maxseqlen, rope_theta=float(theta), sparsity_threshold=sparsity_threshold,
-                                device=dev, dtype=next(attn.parameters()).dtype, make_proj=False)
+                                device=dev, dtype=next(attn.parameters()).dtype, make_proj=False, compact=compact)
         # plain attributes, like the reference's (ML:1440-1466): they do not follow module.to(); use set_devices
         object.__setattr__(attn, "kvq", core)
         object.__setattr__(attn, "kcache", core.kcache)

@@ -156,6 +156,32 @@ def test_command_line_driver_and_generate(gpu, tmp_path, capsys):
     assert ids[:12] == prompt[0].tolist() and 14 <= len(ids) <= 20
 
 
+def test_compact_outlier_format_through_the_model(gpu, tmp_path):
+    """patch_llama(compact=True): the opt-in 4-byte outlier entries through the whole model path (parallel prefill pack,
+    GPU-resident decode); PPL next to the reference format's -- the residuals are rounded to fp16, nothing else changes"""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvquant_amd import calibrate, llama as kl
+    torch.manual_seed(5)
+    cfg = LlamaConfig(vocab_size=512, hidden_size=1024, intermediate_size=512, num_hidden_layers=2,
+                      num_attention_heads=8, num_key_value_heads=8, max_position_embeddings=256,
+                      attention_bias=False, tie_word_embeddings=False)
+    model = LlamaForCausalLM(cfg).half().to(gpu).eval()
+    g = torch.Generator().manual_seed(6)
+    quant = calibrate.calibrate_llama(model, [torch.randint(0, 512, (1, 256), generator=g) for _ in range(2)], bits=4)
+    ids = torch.randint(0, 512, (1, 96), generator=g)
+    res = {}
+    for compact in (False, True):
+        kl.kvquant_config(model.config, abits=4, include_sparse=True, maxseqlen=128, first_few_fp16=0)
+        kl.patch_llama(model, sparsity_threshold=0.99, compact=compact)
+        kl.load_quantizers(model, quant, True, 0.99)
+        assert model.model.layers[0].self_attn.vcache.compact == compact
+        ppl_tok = kl.benchmark(model, ids, check=True)["ppl"]
+        kl.reset_caches(model)
+        res[compact] = (ppl_tok, kl.prefill_then_decode(model, ids, 48, check=True)["ppl"])
+    for a, b in zip(res[False], res[True]):
+        assert math.isfinite(b) and abs(b - a) / a < 5e-3, res
+
+
 def _fresh(kl, mdir, qpath, gpu):
     m = kl.get_model(str(mdir), 64, 128, 4, True, 1).to(gpu).eval()
     kl.patch_llama(m)
