@@ -124,3 +124,75 @@ def test_forward_runs_with_projections():
     y1 = att((torch.randn(1, 1, C, device=dev) * 0.5).half())
     assert y1.shape == (1, 1, C) and torch.isfinite(y1).all()
     assert att.kcache.klen == 13
+
+
+@pytest.mark.parametrize("name", ["ref_attention_nuq4", "ref_attention_nuq3_sink5"])
+def test_replay_reference_attention_module(name):
+    """KVQuantAttention against fixtures made by EXECUTING the reference's own LlamaAttention.forward (ML:1388-1760;
+    tests/golden/gen_attention.py: prefill 40 tokens + 6 decode tokens, first_few_fp16 in {0, 5}).  The post-projection
+    states the reference module saw are replayed through attend(): every call's attention output (the input of o_proj)
+    within 1e-3 in decode (the prefill branch is an fp16 matmul chain there and the MFMA flash kernel here: 2e-2), and
+    the state the calls leave behind -- packed caches, outlier rows, per-token codebooks -- bit for bit."""
+    import os
+    import numpy as np
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd.attention import KVQuantAttention
+    from tests import attn_fixture
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    bits, sinks, S, steps, max_len = int(g["bits"]), int(g["sinks"]), int(g["S"]), int(g["steps"]), int(g["max_len"])
+    dev = torch.device("cuda")
+    w = attn_fixture.make_weights(int(g["seed"]))
+    assert abs(attn_fixture.checksum(w) - float(g["weights_checksum"])) < 1e-6 * float(g["weights_checksum"])
+    quant = (g["q_upper"], g["q_lower"], [g["q_centroids"]])
+
+    def build():
+        att = KVQuantAttention(hidden_size=C, num_heads=H, abits=bits, include_sparse=True, first_few_fp16=sinks,
+                               maxseqlen=max_len, rope_theta=float(g["theta"]), device=dev)
+        with torch.no_grad():
+            for n in ("q", "k", "v", "o"):
+                getattr(att, n + "_proj").weight.copy_(w[n].to(dev))
+        att.load_quantizers(quant, quant)
+        return att
+
+    def st(x, a, b):
+        return torch.from_numpy(x[a:b]).view(1, b - a, H, HD).transpose(1, 2).contiguous().to(dev)
+
+    att = build()
+    ctx = torch.from_numpy(g["ctx"]).float()
+    with torch.no_grad():
+        o = att.attend(st(g["q_states"], 0, S), st(g["k_states"], 0, S), st(g["v_states"], 0, S))
+        # (the fixture's prefill is the reference's EAGER branch: q.K^T rounded to fp16 before the softmax, ML:1594-1596 --
+        #  scores of +-10 carry 1e-2 of rounding there; the flash kernel keeps them in fp32 like flash-attn does in the
+        #  deployed LlamaFlashAttention2)
+        assert util.rel_err(o.float().cpu().reshape(S, -1), ctx[:S]) < 2e-2
+        for i in range(steps):
+            t = S + i
+            o = att.attend(st(g["q_states"], t, t + 1), st(g["k_states"], t, t + 1), st(g["v_states"], t, t + 1))
+            err = util.rel_err(o.float().cpu().reshape(1, -1), ctx[t:t + 1])
+            assert err < 1e-3, (i, err)
+    L = int(g["L"])
+    kq, vq = att.kcache, att.vcache
+    assert kq.klen == S + steps and vq.vlen == S + steps
+    assert np.array_equal(g["kcache"], kq.kcache[:, :, :L].cpu().numpy())
+    assert np.array_equal(g["vcache"], vq.vcache[:, :, :L].cpu().numpy())
+    assert np.array_equal(g["k_outlier_indices"], kq.outlier_indices[:L].cpu().numpy())
+    assert np.array_equal(g["v_outlier_indices"], vq.outlier_indices[:L].cpu().numpy())
+    assert np.array_equal(g["k_outliers"].view(np.int32), kq.outliers[:L].cpu().numpy().view(np.int32))
+    assert np.array_equal(g["v_outliers"].view(np.int32), vq.outliers[:L].cpu().numpy().view(np.int32))
+    assert np.array_equal(g["v_lookup_table"].view(np.int32), vq.lookup_table[:L].cpu().numpy().view(np.int32))
+    if sinks:
+        # post-RoPE sink keys: cos / sin come from the device's libm here and the host's there -- one fp16 ulp
+        assert torch.allclose(att.kcache_fp16.float().cpu(), torch.from_numpy(g["kcache_fp16"]).float(), rtol=2e-3, atol=2e-3)
+        assert torch.equal(att.vcache_fp16.cpu(), torch.from_numpy(g["vcache_fp16"]))
+    # the whole module from the hidden states (projections on this GPU: their fp16 rounding differs from the host's)
+    att2 = build()
+    hid = torch.from_numpy(g["hidden"]).to(dev)
+    ref_out = torch.from_numpy(g["out"]).float()
+    with torch.no_grad():
+        y = att2(hid[:, :S])
+        assert util.rel_err(y.float().cpu().reshape(S, -1), ref_out[:S]) < 1e-2
+        for i in range(steps):
+            t = S + i
+            y = att2(hid[:, t:t + 1])
+            assert util.rel_err(y.float().cpu().reshape(1, -1), ref_out[t:t + 1]) < 1e-2, i
