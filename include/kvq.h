@@ -156,7 +156,8 @@ KVQ_API int kvq_append_k_fused(int bits, int32_t *mat, const float *lut,
                        int thr_k, int H, int hd, int64_t max_len, int64_t col,
                        float *outliers_t, int32_t *outlier_idx_t, void *stream);
 
-/* Options of the fused V appends (host struct, NULL = all defaults).
+/* Options of the fused V appends (host struct).  NULL = the reference's behaviour: no Q-Norm, reference_tie_quirk = 1
+ * (codes bit-identical to vecquant{b}appendvecVsparse on every token).
  *  - Q-Norm (modeling_llama.py:1116-1118, 1153-1156, 1237-1240, 1369-1375): lut_rows2 != NULL makes the kernel write
  *    the second per-token codebook row lut_rows2[col] = (lut_sorted*normscale + normoffset)*sf + off next to
  *    lut_rows[col]; zp_from_rows2 != 0 makes the sparse residuals refer to lut_rows2[col][zero code] instead of
@@ -165,8 +166,9 @@ KVQ_API int kvq_append_k_fused(int bits, int32_t *mat, const float *lut,
  *    STRICTLY outside [22nd smallest, 22nd largest] (KCU:2084), while its glue stores the 21 largest / smallest as
  *    sparse residuals (modeling_llama.py:1093-1096).  When the 21st and 22nd largest values are equal -- one token in
  *    ten for fp16 activations -- that element keeps its nearest code AND gets a residual: it is counted twice
- *    (SURVEY App. A.5).  0 (default): an element is clipped iff it is stored sparse, which is what the reference's
- *    simulated path computes (simquant_module_quantizer.py:95-108, 347-350).  1: replicate the double count. */
+ *    (SURVEY App. A.5).  1 (what NULL options mean): replicate that, as kvquant_amd.cache.QuantV does by default.
+ *    0: an element is clipped iff it is stored sparse, which is what the reference's simulated path computes
+ *    (simquant_module_quantizer.py:95-108, 347-350). */
 typedef struct kvq_vopts {
   float *lut_rows2;      /* device, float [max_len][2^bits], or NULL */
   float normscale;
@@ -303,6 +305,24 @@ KVQ_API int kvq_mix_v_softmax(int bits, const float *scores, const float *parts,
                       float inv_sqrt_hd, const uint16_t *sink_scores, uint16_t *sink_probs,
                       int n_sink, const uint16_t *v_sink, float *probs, const int32_t *mat, float *mul,
                       const float *lut_rows, int H, int hd, int64_t L, int64_t max_len,
+                      const float *outliers, const int32_t *outlier_idx, int n_out,
+                      int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
+/* kvq_mix_v_softmax on the affine structure of the per-token codebooks (kvq_mix_va.hip): every row of lut_rows is
+ * table * sf_t + off_t (modeling_llama.py:1113; kvq_append_v_fused writes them so), hence
+ *   sum_t p_t * lut_rows[t][code] = sum_t (p_t * sf_t) * table[code] + sum_t p_t * off_t :
+ * one constant table in LDS, indexed by two codes at a time, instead of a 64-byte row per token.  sf_t / off_t are
+ * recovered from the stored rows (first and last entry); the cache format is the reference's.  table: device float
+ * [2^bits], the sorted codebook the rows were built from (QuantV.lut; the Q-Norm'ed one when lut_rows is
+ * lookup_table2).  Agrees with kvq_mix_v_softmax to the rounding of the rows (~1e-7 relative per term; the north-star
+ * tolerance of p.V is 1e-3).  3 and 4 bit, max_len % 4 == 0; everything else (and table == NULL) runs
+ * kvq_mix_v_softmax.  workspace: kvq_mix_v_affine_workspace_bytes(bits, H, hd, L). */
+KVQ_API int kvq_mix_v_affine_supported(int bits, int H, int hd, int64_t L, int64_t max_len);
+KVQ_API size_t kvq_mix_v_affine_workspace_bytes(int bits, int H, int hd, int64_t L);
+KVQ_API int kvq_mix_v_softmax_affine(int bits, const float *scores, const float *parts, int n_parts,
+                      float inv_sqrt_hd, const uint16_t *sink_scores, uint16_t *sink_probs,
+                      int n_sink, const uint16_t *v_sink, float *probs, const int32_t *mat, float *mul,
+                      const float *lut_rows, const float *table, int H, int hd, int64_t L, int64_t max_len,
                       const float *outliers, const int32_t *outlier_idx, int n_out,
                       int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -407,7 +407,7 @@ class QuantV(nn.Module):
         taking them from a table the kernel does not read would reconstruct every prompt outlier as
         x + lut1[z] - lut2[z].)  None without Q-Norm."""
         if not self.norm:
-            return (None, 1.0, 0.0, False, True) if self.reference_tie_quirk else None
+            return None if self.reference_tie_quirk else (None, 1.0, 0.0, False, False)     # (NULL options = the reference's quirk)
         return (self.lookup_table2, self._ns, self._no, self.bits == 2, self.reference_tie_quirk)
 
     def mix_table(self):
@@ -550,6 +550,9 @@ FUSE_SOFTMAX_INTO_MIX_V = False
 # head's rows and by the one that owned its token's outliers for ALL heads; since a workgroup takes the outliers of its
 # own heads only, it wins at every length (profiles/r03_b_fused_softmax.txt: 128K 6.12 -> 5.98 ms/step).  Env: A/B runs.
 FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", str(1 << 62)))
+# The fused p.V kernel reads ONE constant table (kvq_mix_va.hip: the per-token rows are affine images of QuantV.lut);
+# env KVQ_MIX_ROWS=1: the per-row kernel it replaces (A/B runs)
+MIX_PER_ROW = os.environ.get("KVQ_MIX_ROWS", "0") == "1"
 
 
 def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
@@ -594,8 +597,8 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         out = torch.empty((1, H, vc.head_dim), dtype=torch.float32, device=kc.device)
         sink_probs = None if sinks is None else torch.empty_like(sink_scores)
         L = kpos + 1
-        ops.decode_step(cached[1], kpos, q, k, v, out, FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO, sinks, v_sink,
-                        sink_probs)
+        fuse = FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO
+        ops.decode_step(cached[1], kpos, q, k, v, out, (2 if MIX_PER_ROW else 1) if fuse else 0, sinks, v_sink, sink_probs)
         kc.klen += 1
         vc.vlen += 1
         return out, sink_probs
@@ -613,7 +616,8 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         sink_probs = ops.score_k_mix_v(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
                                        kc.outliers, kc.outlier_indices, inv, vc.vcache, out,
                                        vc.mix_table(), vc.outliers, vc.outlier_indices, sink_scores, kc.outliers_t,
-                                       kc.outlier_indices_t, v_sink)
+                                       kc.outlier_indices_t, v_sink,
+                                       None if (MIX_PER_ROW or vc.mix_table() is not vc.lookup_table) else vc.lut)
         return out, sink_probs
     probs, sink_probs = ops.score_k_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
                                             kc.outliers, kc.outlier_indices, inv, sink_scores,
@@ -645,6 +649,8 @@ def shard_attention(kc, vc, q, k=None, v=None, pos_base=0, record=None):
         raise ValueError("shard_attention needs include_sparse caches")
     if kc.first_few_fp16 > 0:
         raise ValueError("shard_attention: fp16 attention-sink tokens are not supported on a sharded context")
+    if getattr(kc, "compact", False) or getattr(vc, "compact", False):
+        raise NotImplementedError("shard_attention reads the reference outlier format; compact caches go through decode_kv")
     bits, H, hd = kc.bits, kc.num_heads, vc.head_dim
     if record is None:
         record = torch.empty(shard_record_floats(H, hd), dtype=torch.float32, device=kc.device)

@@ -601,6 +601,7 @@ static AppendArgs v_args(int32_t *mat, float *lut_rows, const float *lut_sorted,
                         col);
   a.lut_rows = lut_rows;
   a.lut_sorted = lut_sorted;
+  a.tie_quirk = 1;          // NULL options = the reference's own arithmetic (include/kvq.h: kvq_vopts)
   if (norm != nullptr) {
     a.tie_quirk = norm->reference_tie_quirk;
     if (norm->lut_rows2 != nullptr) {

@@ -306,6 +306,7 @@ def _warp_logits(logits, temperature, top_k, top_p):
     return logits
 
 
+@torch.no_grad()
 def generate(model, input_ids, max_length=None, max_new_tokens=None, eos_token_id=None, pad_token_id=None,
              do_sample=False, temperature=1.0, top_k=50, top_p=1.0, min_length=0, generator=None):
     """Decoding with the compressed cache: the reference's `model.generate(..., kvquant=True)`

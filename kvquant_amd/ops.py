@@ -62,7 +62,10 @@ def _workspace(device, nbytes, slot="mix"):
     key = (slot, idx, torch.cuda.current_stream(idx).cuda_stream)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
-        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        # grow geometrically: the decode workspaces grow by a few hundred bytes per token, and a buffer sized exactly
+        # would be replaced every other token once it is past the 1 MiB floor (allocator churn in the hot path)
+        grown = 0 if w is None else w.numel() + (w.numel() >> 1)
+        w = torch.empty(max(nbytes, grown, 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = w
     return w
 
@@ -471,7 +474,7 @@ def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, out
 
 def score_k_mix_v(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices, inv_sqrt_hd,
                   vmat, out, vlut_rows, voutliers, voutlier_indices, sink_scores=None, koutliers_t=None,
-                  koutlier_indices_t=None, v_sink=None):
+                  koutlier_indices_t=None, v_sink=None, vtable=None):
     """q.K^T (tables already in `ws`) -> softmax -> p.V of one decode token in two streaming launches + the slab
     reduce: the score kernel writes raw scores and per-tile softmax partials, the p.V kernel normalises on the way
     (kvq_mix_v_softmax).  scores [1, H, L] scratch, out f32 [1, H, hd].  Returns sink_probs (f16 [H, n_sink]) or None."""
@@ -486,33 +489,35 @@ def score_k_mix_v(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers,
     parts = score_k_prepared_softmax(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices,
                                      inv_sqrt_hd, n_parts, koutliers_t, koutlier_indices_t)
     return mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, vmat, out, vlut_rows, L, voutliers,
-                         voutlier_indices, sink_scores, v_sink)
+                         voutlier_indices, sink_scores, v_sink, vtable)
 
 
 def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows, L, outliers, outlier_indices,
-                  sink_scores=None, v_sink=None):
-    """kvq_mix_v_softmax: raw scores [1, H, L] + the score kernel's softmax partials -> mul f32 [1, H, hd]
+                  sink_scores=None, v_sink=None, table=None):
+    """kvq_mix_v_softmax[_affine]: raw scores [1, H, L] + the score kernel's softmax partials -> mul f32 [1, H, hd]
     (overwritten; with v_sink f16 [H, n_sink, 128] it includes the sink tokens' share); returns sink_probs
-    (f16 [H, n_sink]) or None."""
+    (f16 [H, n_sink]) or None.  table (f32 [2^bits], the sorted codebook every row of lut_rows is an affine image of):
+    the constant-table kernel (kvq_mix_va.hip); None: the per-row kernel."""
     H, hd, max_len = _cache_dims(mat, bits)
     n_sink = 0 if sink_scores is None else sink_scores.shape[1]
     sink_probs = None if n_sink == 0 else torch.empty_like(sink_scores)
     with _Dev(mat):
-        nbytes = _L().kvq_mix_v_workspace_bytes(bits, 1, H, hd, int(L))
+        nbytes = _L().kvq_mix_v_affine_workspace_bytes(bits, H, hd, int(L))
         wsv = _workspace(mat.device, nbytes)
         # room for the probabilities of the library's two-pass route: always handed over, so that the shapes its
         # streaming kernel does not take (unaligned rows or tables, H > 128, more than 2^31 packed words, ...) fall back
         # inside the library whatever its predicate is -- the two checks cannot drift apart (H * L * 4 bytes, cached)
         probs = _workspace(mat.device, H * int(L) * 4, slot="probs")
-        _lib.check(_L().kvq_mix_v_softmax(
+        _lib.check(_L().kvq_mix_v_softmax_affine(
             bits, _f(scores, "scores"), parts.data_ptr(), n_parts, float(inv_sqrt_hd),
             None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"),
             None if n_sink == 0 else sink_probs.data_ptr(), n_sink,
             None if v_sink is None else _chk(v_sink, torch.float16, "v_sink"),
             None if probs is None else probs.data_ptr(),
-            _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), H, hd, int(L), max_len,
-            _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outliers.shape[1], 0, wsv.data_ptr(),
-            wsv.numel(), _stream()), "kvq_mix_v_softmax")
+            _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), None if table is None else _f(table, "lut"),
+            H, hd, int(L), max_len,
+            _fo(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outlier_indices.shape[1], 0,
+            wsv.data_ptr(), wsv.numel(), _stream()), "kvq_mix_v_softmax_affine")
     return sink_probs
 
 
@@ -592,7 +597,7 @@ def decode_step(layer, col, q, k, v, out, fuse_softmax, sinks=None, v_sink=None,
         _lib.check(_L().kvq_decode_step(
             ctypes.byref(layer), int(col), int(col), qp, kp, vp, kh, None if sk is None else ctypes.byref(sk),
             None if v_sink is None else _chk(v_sink, torch.float16, "v_sink"),
-            None if sink_probs is None else sink_probs.data_ptr(), _f(out, "out"), 1 if fuse_softmax else 0,
+            None if sink_probs is None else sink_probs.data_ptr(), _f(out, "out"), int(fuse_softmax),
             base, ws.numel() - (base - ws.data_ptr()), _stream()), "kvq_decode_step")
 
 

@@ -13,7 +13,8 @@ import torch
 import torch.nn as nn
 
 
-def make_model(layers=2, vocab=32000, hidden=4096, heads=32, inter=2048, seed=0, device="cuda", maxseqlen=4096, **knobs):
+def make_model(layers=2, vocab=32000, hidden=4096, heads=32, inter=2048, seed=0, device="cuda", maxseqlen=4096,
+               dtype=torch.float16, **knobs):
     from transformers import LlamaConfig, LlamaForCausalLM
     from kvquant_amd import llama as kl
     cfg = LlamaConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
@@ -21,8 +22,55 @@ def make_model(layers=2, vocab=32000, hidden=4096, heads=32, inter=2048, seed=0,
                       attention_bias=False, tie_word_embeddings=False)
     cfg = kl.kvquant_config(cfg, maxseqlen=maxseqlen, **knobs)
     torch.manual_seed(seed)
-    model = LlamaForCausalLM(cfg).half().to(device).eval()
+    model = LlamaForCausalLM(cfg).to(dtype).to(device).eval()
     return model
+
+
+class MarkovStream:
+    """A synthetic language with a KNOWN entropy: an order-1 Markov chain over the vocabulary in which every token has
+    `fan` possible successors with Zipf(`alpha`) probabilities (seeded).  fan = 8, alpha = 1.2: 1.70 nats per token, i.e.
+    an ideal perplexity of 5.48 -- the regime of wikitext-2 on LLaMA-2-7B (5.47), so that "within 0.01 PPL" means what
+    it means in BASELINE.json instead of being measured on a random-init model whose PPL is the vocabulary size."""
+
+    def __init__(self, vocab, fan=8, alpha=1.2, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.vocab, self.g = vocab, g
+        self.succ = torch.randint(0, vocab, (vocab, fan), generator=g)
+        p = 1.0 / torch.arange(1, fan + 1, dtype=torch.float64) ** alpha
+        self.p = (p / p.sum()).float()
+        self.entropy = float(-(self.p.double() * self.p.double().log()).sum())
+
+    def sample(self, batch, length):
+        cur = torch.randint(0, self.vocab, (batch,), generator=self.g)
+        out = [cur]
+        ks = torch.multinomial(self.p.expand(batch, -1), length - 1, replacement=True, generator=self.g)   # [batch, length-1]
+        for t in range(length - 1):
+            cur = self.succ[cur, ks[:, t]]
+            out.append(cur)
+        return torch.stack(out, dim=1)
+
+
+def train_markov(model, stream, steps=300, batch=8, length=512, lr=1e-3, warmup=20, log=None):
+    """a few hundred AdamW steps (fp32 weights) on the stream: enough for a 2-layer model to learn the transition table to
+    a perplexity of O(10)"""
+    dev = next(model.parameters()).device
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.0)
+    last = None
+    for step in range(steps):
+        for gq in opt.param_groups:
+            gq["lr"] = lr * min(1.0, (step + 1) / warmup) * (0.1 + 0.9 * 0.5 * (1 + __import__("math").cos(3.141592653589793 * step / steps)))
+        ids = stream.sample(batch, length).to(dev)
+        loss = model(ids, labels=ids, use_cache=False).loss
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        last = float(loss.detach())
+        if log is not None and (step % 50 == 0 or step == steps - 1):
+            log("train step %d loss %.3f (ppl %.1f)" % (step, last, __import__("math").exp(last)))
+    model.eval()
+    return last
 
 
 class FakeQuantLinear(nn.Module):
@@ -143,13 +191,43 @@ def kernel_path_ppl(model, ids, quantizers, sparsity_threshold=0.99, norm=False,
     return kl.benchmark(m, ids, check=True)["ppl"]
 
 
-def run(layers=2, n_tokens=512, bits=4, first_few_fp16=0, vocab=32000, seed=0, n_prompt=0, norm=False, device="cuda"):
+_TRAINED = {}
+
+
+def trained_model(layers, vocab, seed, device, maxseqlen, train_steps, hidden=4096, heads=32, inter=2048, log=None, **knobs):
+    """the seeded model after `train_steps` steps on the seeded Markov stream (cached per process: the configurations of a
+    test session share one training run), as an fp16 copy with the given cache knobs"""
+    key = (layers, vocab, seed, str(device), train_steps, hidden, heads, inter)
+    if key not in _TRAINED:
+        m = make_model(layers=layers, vocab=vocab, hidden=hidden, heads=heads, inter=inter, seed=seed, device=device,
+                       maxseqlen=8192, dtype=torch.float32)
+        stream = MarkovStream(vocab, seed=seed)
+        loss = train_markov(m, stream, steps=train_steps, log=log)
+        _TRAINED[key] = (m.half().state_dict(), stream, loss)
+        del m
+        if str(device).startswith("cuda"):
+            torch.cuda.empty_cache()
+    sd, stream, loss = _TRAINED[key]
+    model = make_model(layers=layers, vocab=vocab, hidden=hidden, heads=heads, inter=inter, seed=seed, device=device,
+                       maxseqlen=maxseqlen, **knobs)
+    model.load_state_dict(sd)
+    return model, stream, loss
+
+
+def run(layers=2, n_tokens=512, bits=4, first_few_fp16=0, vocab=32000, seed=0, n_prompt=0, norm=False, device="cuda",
+        train_steps=0, hidden=4096, heads=32, inter=2048, log=None):
     from kvquant_amd import calibrate
-    model = make_model(layers=layers, vocab=vocab, seed=seed, device=device, maxseqlen=n_tokens + 64, abits=bits,
-                       include_sparse=True, first_few_fp16=first_few_fp16)
     g = torch.Generator().manual_seed(seed)
-    ids = torch.randint(0, vocab, (1, n_tokens), generator=g).to(device)
-    calib = torch.randint(0, vocab, (1, 2048), generator=g).to(device)
+    if train_steps > 0:
+        model, stream, _ = trained_model(layers, vocab, seed, device, n_tokens + 64, train_steps, hidden=hidden, heads=heads,
+                                         inter=inter, log=log, abits=bits, include_sparse=True, first_few_fp16=first_few_fp16)
+        ids = stream.sample(1, n_tokens).to(device)
+        calib = stream.sample(1, 2048).to(device)
+    else:
+        model = make_model(layers=layers, vocab=vocab, hidden=hidden, heads=heads, inter=inter, seed=seed, device=device,
+                           maxseqlen=n_tokens + 64, abits=bits, include_sparse=True, first_few_fp16=first_few_fp16)
+        ids = torch.randint(0, vocab, (1, n_tokens), generator=g).to(device)
+        calib = torch.randint(0, vocab, (1, 2048), generator=g).to(device)
     quantizers = calibrate.calibrate_llama(model, calib, bits=bits, include_sparse=True, sparsity_threshold=0.99, norm=norm)
     base = ppl_full_sequence(model, ids)
     ff = first_few_fp16 if first_few_fp16 else -1
@@ -157,6 +235,6 @@ def run(layers=2, n_tokens=512, bits=4, first_few_fp16=0, vocab=32000, seed=0, n
     simd = sim_deploy_arith_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm)
     ker = kernel_path_ppl(model, ids, quantizers, norm=norm, n_prompt=n_prompt)
     return {"layers": layers, "tokens": n_tokens, "bits": bits, "first_few_fp16": first_few_fp16, "vocab": vocab,
-            "n_prompt": n_prompt, "norm": norm, "ppl_fp16": base, "ppl_sim": sim, "ppl_sim_deploy_arith": simd,
+            "n_prompt": n_prompt, "norm": norm, "train_steps": train_steps, "ppl_fp16": base, "ppl_sim": sim, "ppl_sim_deploy_arith": simd,
             "ppl_kernel": ker, "delta": ker - sim, "rel_delta": (ker - sim) / sim,
             "rel_delta_vs_deploy_arith": (ker - simd) / simd}

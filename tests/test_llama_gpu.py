@@ -135,6 +135,14 @@ def test_command_line_driver_and_generate(gpu, tmp_path, capsys):
     prompt = torch.randint(0, 512, (1, 12), generator=g)
     seq = kl.generate(m2, prompt, max_new_tokens=6)
     assert seq.shape == (1, 18) and torch.equal(seq[:, :12].cpu(), prompt)
+    assert not seq.requires_grad                                   # generate() runs under no_grad (HF's does)
+    with torch.enable_grad():
+        m3 = _fresh(kl, mdir, qpath, gpu)
+        hooked = []
+        h = m3.lm_head.register_forward_hook(lambda mod, i, o: hooked.append(o.requires_grad))
+        kl.generate(m3, prompt, max_new_tokens=2)
+        h.remove()
+    assert hooked and not any(hooked), "generate() built an autograd graph"
     assert m2.model.layers[0].self_attn.kcache.klen == 17      # the last generated token was never fed back
     seq2 = kl.generate(_fresh(kl, mdir, qpath, gpu), prompt, max_length=15)
     assert seq2.shape == (1, 15) and torch.equal(seq2, seq[:, :15])

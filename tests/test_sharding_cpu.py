@@ -164,3 +164,85 @@ def test_token_sharded_step_merges_exactly(world):
     for p in procs:
         p.join(timeout=60)
     assert all(err < 1e-5 for _, err in res), res
+
+
+# ---- the op order of StreamPipeline under the strictest p2p semantics --------------------------------
+class _RecordingDist:
+    """stands in for torch.distributed inside kvquant_amd.sharding: records the point-to-point calls of ONE rank in
+    issue order, moves no data"""
+
+    class _Req:
+        def wait(self):
+            return True
+
+    def __init__(self, rank):
+        self.rank, self.ops = rank, []
+
+    def isend(self, t, dst, group=None):
+        self.ops.append(("send", dst))
+        return self._Req()
+
+    def irecv(self, t, src, group=None):
+        self.ops.append(("recv", src))
+        return self._Req()
+
+    def send(self, t, dst, group=None):
+        self.ops.append(("send", dst))
+
+    def recv(self, t, src, group=None):
+        self.ops.append(("recv", src))
+
+
+def _pipeline_op_order(W, streams, steps, monkeypatch):
+    import torch
+    from kvquant_amd import sharding
+    template = torch.zeros(1, 1, 8)
+    per_rank = []
+    for r in range(W):
+        rec = _RecordingDist(r)
+        monkeypatch.setattr(sharding, "dist", rec)
+        pipe = sharding.StreamPipeline(lambda s, st, x: x, streams, rank=r, world=W)
+        pipe.run(steps, lambda s, st: template.clone(), template)
+        per_rank.append(rec.ops)
+    return per_rank
+
+
+def _drains_under_rendezvous(per_rank):
+    """RCCL / NCCL run the p2p operations of a communicator in issue order on one stream, and a send finishes only
+    against its matching receive.  Strictest model: an operation completes only while it AND its match are at the head of
+    their ranks' queues (no buffering at all, the k-th send a -> b matches the k-th receive on b from a).  Returns True
+    when every queue drains, i.e. the wait-for graph never has a cycle."""
+    heads = [0] * len(per_rank)
+    progressed = True
+    while progressed:
+        progressed = False
+        for a, ops in enumerate(per_rank):
+            if heads[a] >= len(ops):
+                continue
+            kind, b = ops[heads[a]]
+            if heads[b] >= len(per_rank[b]):
+                continue
+            kb, peer = per_rank[b][heads[b]]
+            if peer == a and kb != kind:       # send meets receive: both complete (in-order per pair by construction)
+                heads[a] += 1
+                heads[b] += 1
+                progressed = True
+    return all(h == len(o) for h, o in zip(heads, per_rank))
+
+
+@pytest.mark.parametrize("W", [2, 3, 4, 8])
+def test_stream_pipeline_op_order_cannot_deadlock(W, monkeypatch):
+    """The exact isend / irecv / recv sequence that StreamPipeline.run issues on every rank (recorded by running it),
+    replayed under zero-buffer rendezvous semantics: it must drain for 1, W and 2W+5 streams (the last exercises the
+    bounded send window).  A control with rank 0's final receive of an item posted BEFORE that item's first send (lag 0)
+    must NOT drain -- the model can tell the difference."""
+    for streams in (1, W, 2 * W + 5):
+        per_rank = _pipeline_op_order(W, streams, 3, monkeypatch)
+        n_items = 3 * streams
+        assert sum(1 for k, _ in per_rank[0] if k == "send") == n_items
+        assert _drains_under_rendezvous(per_rank), (W, streams)
+    per_rank = _pipeline_op_order(W, W, 3, monkeypatch)
+    recvs = [o for o in per_rank[0] if o[0] == "recv"]
+    sends = [o for o in per_rank[0] if o[0] == "send"]
+    per_rank[0] = [o for pair in zip(recvs, sends) for o in pair]      # receive the final of item i, THEN send item i
+    assert not _drains_under_rendezvous(per_rank)

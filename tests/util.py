@@ -108,3 +108,24 @@ def ref_pack_k_agrees_where_defined(ref, name, lut, k, lo, hi, ours_mat, ours_re
         racy_words.append(int(bad_w.sum()))
         racy_vals.append(int(bad_v.sum()))
     return racy_words, racy_vals
+
+
+def unpack_codes(mat, bits, L):
+    """codes int64 [C, L] of the first L columns of a packed cache int32 [H, hd/32*bits, max_len] (CPU tensor);
+    bit layouts of KCU:1240-1244 (4 bit), 1395-1424 (3 bit), 2712-2716 (2 bit)"""
+    Hh, W, _ = mat.shape
+    w = (mat[:, :, :L].to(torch.int64) & 0xffffffff).reshape(Hh, W // bits, bits, L)      # 32-channel groups
+    out = torch.empty((Hh, W // bits, 32, L), dtype=torch.int64)
+    for i in range(32):
+        if bits == 4:
+            out[:, :, i] = (w[:, :, i // 8] >> (4 * (i % 8))) & 15
+        elif bits == 2:
+            out[:, :, i] = (w[:, :, i // 16] >> (2 * (i % 16))) & 3
+        else:
+            b = 3 * i
+            lo, sh = b // 32, b % 32
+            val = w[:, :, lo] >> sh
+            if sh > 29:
+                val = val | (w[:, :, lo + 1] << (32 - sh))
+            out[:, :, i] = val & 7
+    return out.reshape(-1, L)
