@@ -30,7 +30,7 @@ static StepPlan plan_step(int bits, int H, int hd, int64_t L) {
   p.parts_off = p.score_ws;
   p.parts_b = align256((size_t)H * (p.n_parts > 0 ? p.n_parts : 1) * 8);
   p.mix_off = p.parts_off + p.parts_b;
-  p.mix_b = align256(kvq_mix_v_workspace_bytes(bits, 1, H, hd, L));
+  p.mix_b = align256(kvq_mix_v_affine_workspace_bytes(bits, H, hd, L));   // (>= kvq_mix_v_workspace_bytes)
   p.scores_off = p.mix_off + p.mix_b;
   p.scores_b = align256((size_t)H * L * 4);
   p.probs_off = p.scores_off + p.scores_b;
@@ -111,9 +111,12 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
   if (fuse_softmax) {
     // (event 2 goes behind the small softmax-merge launch, in front of the p.V kernel: kvq_step_mark_pv below)
     mark2_pending = true;
-    rc = kvq_mix_v_softmax(bits, scores, parts, p.n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs, ly->vmat,
-                           out, vrows, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0, ws + p.mix_off, p.mix_b,
-                           stream);
+    // the affine form reads ONE constant table: the sorted codebook the rows are images of (fuse_softmax == 2, or rows
+    // of another table -- Q-Norm at 2 bit: the per-row kernel)
+    const float *vtable = (fuse_softmax == 2 || ly->v_mix_rows) ? nullptr : ly->vlut_sorted;
+    rc = kvq_mix_v_softmax_affine(bits, scores, parts, p.n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs,
+                                  ly->vmat, out, vrows, vtable, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0,
+                                  ws + p.mix_off, p.mix_b, stream);
     if (mark2_pending) { mark2_pending = false; record(2, st); }   // (a route that does not pass the mark: the whole call)
     record(3, st);
     return rc;

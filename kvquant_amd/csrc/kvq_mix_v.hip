@@ -1378,6 +1378,20 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   return check_launch();
 }
 
+int launch_mix_reduce(const float *partial, float *mul, int n_ranges, int q_len, int C, int accumulate, hipStream_t st) {
+  dim3 rgrid((C + 15) / 16, q_len);
+  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(partial, mul, n_ranges, q_len, C, accumulate);
+  return check_launch();
+}
+int launch_softmax_merge(const float *parts, int n_parts, const void *sink, void *sink_probs, int n_sink, float *mz,
+                         const void *v_sink, float *sink_out, int H, hipStream_t st) {
+  softmax_merge_kernel<<<H, 256, 0, st>>>(parts, n_parts, reinterpret_cast<const __half *>(sink),
+                                          reinterpret_cast<__half *>(sink_probs), n_sink, mz,
+                                          reinterpret_cast<const __half *>(v_sink), sink_out);
+  return check_launch();
+}
+int mix_merge_in_kernel_parts() { return kMergeInKernelParts; }
+
 static size_t ws_bytes(int bits, int q_len, int H, int64_t L) {
   size_t a = bits == 4 ? plan_mix<4>(q_len, H, L).bytes : (bits == 3 ? plan_mix<3>(q_len, H, L).bytes : plan_mix<2>(q_len, H, L).bytes);
   size_t b = plan_mix_rows(bits, q_len, H, L, true).bytes;
