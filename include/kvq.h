@@ -326,6 +326,25 @@ KVQ_API int kvq_mix_v_softmax_affine(int bits, const float *scores, const float 
                       const float *outliers, const int32_t *outlier_idx, int n_out,
                       int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The attention of one decode token over a layer's compressed cache as ONE streaming kernel + a small merge
+ * (kvq_fused_decode.hip): every workgroup takes a 256-token tile through q.K^T (+ RoPE, + K outlier entries: the tile
+ * body of kvq_score_k_prepared_softmax), a tile-local softmax and p.V (+ V outlier entries) of the same tokens; the merge
+ * combines the tiles' (max, sum, partial output) records and the fp16 sink tokens exactly ("flash-decoding" over the
+ * token axis).  Replaces kvq_score_k_prepared_softmax + kvq_mix_v_softmax (KCU:3040-3209, 473-521, 3211-3433, 437-470 and
+ * the softmax between them, modeling_llama.py:1948-1995): the scores never exist in memory.  A probability is rounded
+ * to fp16 relative to its tile's maximum instead of the row's normaliser (same 2^-11 relative rounding; tolerance of the
+ * attention output against the reference pipeline: 1e-3).  score_workspace: the query-premultiplied tables + fp32 query
+ * written by kvq_decode_prologue / kvq_score_k_tables.  Reference outlier formats with the K mirror, n_out <= 48,
+ * H <= 32, max_len % 4 == 0 (kvq_fused_attend_supported); out: float [H][hd]. */
+KVQ_API int kvq_fused_attend_supported(int bits, int H, int hd, int64_t L, int64_t max_len, int n_out);
+KVQ_API size_t kvq_fused_attend_workspace_bytes(int bits, int H, int hd, int64_t L);
+KVQ_API int kvq_fused_attend(int bits, const int32_t *kmat, const float *klut, const void *score_workspace,
+                     const int32_t *vmat, const float *vlut_rows, int H, int hd, int64_t L, int64_t max_len,
+                     float rope_theta, int pos_offset, const float *koutliers_t, const int32_t *kidx_t,
+                     const float *voutliers, const int32_t *vidx, int n_out, float inv_sqrt_hd,
+                     const uint16_t *sink_scores, uint16_t *sink_probs, int n_sink, const uint16_t *v_sink,
+                     float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- one decode token through one layer, one call -------------------------------- */
 
 /* The buffers of one layer's compressed KV cache: what the reference keeps as attributes of QuantK / QuantV
@@ -364,7 +383,9 @@ typedef struct kvq_layer {
  * around QuantK / QuantV.forward_fused_sparse (modeling_llama.py:1930-2000).  q [H][128] (RoPE'd), k, v [H*hd]:
  * all fp32 or all fp16.  sinks / v_sink / sink_probs: the fp16 attention-sink tokens (as kvq_decode_prologue /
  * kvq_softmax_finish), or NULL.  out f32 [H][hd]: the complete attention output.  Scores, probabilities, partials and
- * slabs live in `workspace` (kvq_decode_step_workspace_bytes(bits, H, hd, L) with L = kcol + 1; 256-byte aligned). */
+ * slabs live in `workspace` (kvq_decode_step_workspace_bytes(bits, H, hd, L) with L = kcol + 1; 256-byte aligned).
+ * fuse_softmax: 0 = softmax as its own launch, 1 = inside the p.V kernel, 2 = as 1 with the per-row p.V kernel forced,
+ * 3 = kvq_fused_attend (one kernel for q.K^T, softmax and p.V; shapes it does not take run as 1). */
 KVQ_API size_t kvq_decode_step_workspace_bytes(int bits, int H, int hd, int64_t L);
 KVQ_API int kvq_decode_step(const kvq_layer *layer, int64_t kcol, int64_t vcol, const void *q, const void *k,
                     const void *v, int acts_are_half, const kvq_sinks *sinks, const uint16_t *v_sink,

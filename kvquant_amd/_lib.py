@@ -81,6 +81,10 @@ SIGNATURES = {
     "kvq_mix_v_affine_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
     "kvq_mix_v_softmax_affine": (_i, [_i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64,
                                       _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "kvq_fused_attend_supported": (_i, [_i, _i, _i, _i64, _i64, _i]),
+    "kvq_fused_attend_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
+    "kvq_fused_attend": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i,
+                              _vp, _vp, _vp, _sz, _vp]),
     "kvq_decode_step_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
     "kvq_decode_step": (_i, [_ly, _i64, _i64, _vp, _vp, _vp, _i, _sk, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "kvq_decode_step_events": (_i, [_vp]),

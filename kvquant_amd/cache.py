@@ -550,9 +550,13 @@ FUSE_SOFTMAX_INTO_MIX_V = False
 # head's rows and by the one that owned its token's outliers for ALL heads; since a workgroup takes the outliers of its
 # own heads only, it wins at every length (profiles/r03_b_fused_softmax.txt: 128K 6.12 -> 5.98 ms/step).  Env: A/B runs.
 FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", str(1 << 62)))
-# The fused p.V kernel reads ONE constant table (kvq_mix_va.hip: the per-token rows are affine images of QuantV.lut);
-# env KVQ_MIX_ROWS=1: the per-row kernel it replaces (A/B runs)
-MIX_PER_ROW = os.environ.get("KVQ_MIX_ROWS", "0") == "1"
+# KVQ_MIX_AFFINE=1: the constant-table p.V kernel (kvq_mix_va.hip: the per-token rows are affine images of QuantV.lut) instead
+# of the per-row kernel.  Measured at 128K nuq4 (profiles/r04_mixva_*): 72 us without outlier entries, 91 - 107 us with them
+# (per-row kernel: 87) -- its dense loop is bound by the HBM stream and the outlier phase, not by the look-ups it saves.
+MIX_PER_ROW = os.environ.get("KVQ_MIX_AFFINE", "0") != "1"
+# One kernel for q.K^T + softmax + p.V per 256-token tile and a merge (kvq_fused_decode.hip: kvq_fused_attend) instead of
+# the score / p.V kernel pair.  KVQ_FUSED_ATTEND=0: the separate kernels.
+FUSED_ATTEND = os.environ.get("KVQ_FUSED_ATTEND", "0") == "1"
 
 
 def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
@@ -598,7 +602,8 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         sink_probs = None if sinks is None else torch.empty_like(sink_scores)
         L = kpos + 1
         fuse = FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO
-        ops.decode_step(cached[1], kpos, q, k, v, out, (2 if MIX_PER_ROW else 1) if fuse else 0, sinks, v_sink, sink_probs)
+        mode = (3 if FUSED_ATTEND else (2 if MIX_PER_ROW else 1)) if fuse else 0
+        ops.decode_step(cached[1], kpos, q, k, v, out, mode, sinks, v_sink, sink_probs)
         kc.klen += 1
         vc.vlen += 1
         return out, sink_probs

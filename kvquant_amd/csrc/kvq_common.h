@@ -11,6 +11,7 @@
 
 // measurement hook of kvq_decode_step (kvq_decode_step.hip): the fused p.V route calls it in front of its p.V kernel
 extern "C" void kvq_step_mark_pv(hipStream_t st);
+extern "C" void kvq_step_mark_fused(hipStream_t st);
 
 namespace kvq {
 

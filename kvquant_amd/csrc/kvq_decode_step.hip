@@ -33,6 +33,10 @@ static StepPlan plan_step(int bits, int H, int hd, int64_t L) {
   p.mix_b = align256(kvq_mix_v_affine_workspace_bytes(bits, H, hd, L));   // (>= kvq_mix_v_workspace_bytes)
   p.scores_off = p.mix_off + p.mix_b;
   p.scores_b = align256((size_t)H * L * 4);
+  {   // (the fused kernel keeps its tile slabs and statistics where the other routes keep the scores)
+    const size_t fb = align256(kvq_fused_attend_workspace_bytes(bits, H, hd, L));
+    if (fb > p.scores_b) p.scores_b = fb;
+  }
   p.probs_off = p.scores_off + p.scores_b;
   p.probs_b = p.scores_b;
   p.total = p.probs_off + p.probs_b;
@@ -43,6 +47,7 @@ static StepPlan plan_step(int bits, int H, int hd, int64_t L) {
 static thread_local hipEvent_t *step_events = nullptr;
 
 static thread_local bool mark2_pending = false;
+static thread_local int step_fused_mark = 0;
 static void record(int i, hipStream_t st) {
   if (step_events && step_events[i]) (void)hipEventRecord(step_events[i], st);
 }
@@ -57,6 +62,14 @@ extern "C" {
 void kvq_step_mark_pv(hipStream_t st) {
   if (mark2_pending) {
     mark2_pending = false;
+    record(2, st);
+  }
+}
+
+// called by kvq_fused_attend between its two launches (kvq_fused_decode.hip)
+void kvq_step_mark_fused(hipStream_t st) {
+  if (step_fused_mark) {
+    record(1, st);
     record(2, st);
   }
 }
@@ -100,6 +113,19 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   struct Clear { ~Clear() { step_events = nullptr; } } clear_events_on_exit;
+  if (fuse_softmax == 3 && ly->koutliers_t && ly->voutliers && !ly->v_mix_rows && !ly->klut_score &&
+      kvq_fused_attend_supported(bits, H, hd, L, ly->max_len, n_out)) {
+    // one kernel for q.K^T + softmax + p.V of every 256-token tile, then the merge (events: 0-1 the kernel, 2-3 the merge)
+    record(0, st);
+    step_fused_mark = 1;
+    rc = kvq_fused_attend(bits, ly->kmat, ktab, ws, ly->vmat, ly->vlut_rows, H, hd, L, ly->max_len, ly->rope_theta,
+                          ly->pos_offset, ly->koutliers_t, ly->kidx_t, ly->voutliers, ly->vidx, n_out, inv,
+                          sinks ? sinks->sink_scores : nullptr, sink_probs, n_sink, v_sink, out, ws + p.scores_off, p.scores_b,
+                          stream);
+    step_fused_mark = 0;
+    record(3, st);
+    return rc;
+  }
   record(0, st);
   rc = kvq_score_k_prepared_softmax(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta, ly->pos_offset,
                                     ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws, p.score_ws, inv,

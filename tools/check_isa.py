@@ -245,6 +245,9 @@ def main():
         kernels, problems = check(_compile("kvq_score_k.hip"))
         k2, p2 = check_mix_v(_compile("kvq_mix_v.hip"))
         kernels, problems = kernels + k2, problems + p2
+        # the fused decode kernel runs the mirror score tile body (loads in flight across head iterations) as its K phase
+        k3, p3 = check_cfg(_compile("kvq_fused_decode.hip"), kernel_substr="fused_decode_kernel")
+        kernels, problems = kernels + k3, problems + p3
     print("%d kernels checked, %d problems" % (kernels, len(problems)))
     for p in problems:
         print("  " + p)
