@@ -66,6 +66,8 @@ def parse():
                     help="bracket every N-th layer's two matvec launches with HIP events (1 = all; the events cost time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp16-baseline", action="store_true")
+    ap.add_argument("--no-full-model", action="store_true",
+                    help="skip the full-model leg (random-init LLaMA-2-7B-shaped fp16 weights over the same filled caches)")
     ap.add_argument("--cpu-sample-tokens", type=int, default=8192)
     return ap.parse_args()
 
@@ -376,6 +378,58 @@ def cpu_baseline(bits, sample_tokens, ctx, layers):
                          ck.num_threads(), dt_c, qreps, blk, qthreads, q_total, prefill_tok_s, layers, q_one * 1e3)}
 
 
+def full_model_leg(args, caches, owned, max_len, dev, tokens=8):
+    """BASELINE.md's "full model" column (deployment/llama.py:39-94: `benchmark()` feeds one token at a time through the
+    whole network): a random-init fp16 Llama with the LLaMA-2-7B shape (4096 / 11008 / 32 heads, 13.5 GB of weights for 32
+    layers) patched by kvquant_amd.llama, its attention modules given THE caches this run filled (stream 0), decoding
+    `tokens` tokens at the bench's context.  Weights are random (no checkpoint offline): the time per token is what a
+    real checkpoint would take, the tokens mean nothing.  Returns a dict for the JSON line."""
+    import time as _t
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvquant_amd import llama as kl
+    t0 = _t.time()
+    cfg = LlamaConfig(vocab_size=32000, hidden_size=C, intermediate_size=11008, num_hidden_layers=len(owned),
+                      num_attention_heads=H, num_key_value_heads=H, max_position_embeddings=max(max_len, 4096),
+                      attention_bias=False, tie_word_embeddings=False)
+    kl.kvquant_config(cfg, maxseqlen=64, abits=args.bits, include_sparse=True, first_few_fp16=args.sinks)
+    torch.set_default_dtype(torch.float16)
+    try:
+        with torch.device(dev):
+            model = LlamaForCausalLM(cfg)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    model.eval()
+    kl.patch_llama(model, compact=getattr(args, "compact", False))
+    for i, layer in enumerate(model.model.layers):
+        lay = caches[(0, owned[i])]
+        attn, core = layer.self_attn, layer.self_attn.kvq
+        core.kcache, core.vcache = lay.k, lay.v
+        object.__setattr__(attn, "kcache", lay.k)
+        object.__setattr__(attn, "vcache", lay.v)
+        if args.sinks:
+            core.kcache_fp16, core.vcache_fp16 = lay.k_sink.unsqueeze(0), lay.v_sink.unsqueeze(0)
+    weights_gb = sum(p.numel() * p.element_size() for p in model.parameters()) / 1e9
+    ids = torch.randint(0, 32000, (1, tokens + 2), device=dev)
+    times = []
+    with torch.no_grad():
+        for i in range(tokens + 2):
+            torch.cuda.synchronize()
+            t1 = _t.perf_counter()
+            model(ids[:, i:i + 1], use_cache=False)
+            torch.cuda.synchronize()
+            times.append(_t.perf_counter() - t1)
+    times = sorted(times[2:])
+    med = times[len(times) // 2]
+    del model
+    torch.cuda.empty_cache()
+    return {"tokens_per_s": 1.0 / med, "ms_per_token": med * 1e3, "tokens_timed": tokens, "layers": len(owned),
+            "weights_GB": weights_gb, "ctx": args.ctx,
+            "note": "random-init fp16 LLaMA-2-7B-shaped model (stock HF Llama + kvquant_amd.llama patch), token-by-token "
+                    "decode over the caches of this run (deployment/llama.py:72-88); median of %d steps; includes the "
+                    "projections / MLP weight stream and the Python per-layer overhead of the HF module tree" % tokens,
+            "setup_s": _t.time() - t0}
+
+
 def fp16_matvec_baseline(ctx, dev, iters=10):
     """The un-quantised baseline of the reference's kernel benchmarks (benchmarking/scripts/test_kernel_baselines.py:
     28-61): fp16 K / V of one layer, torch.matmul for q.K^T and p.V (rocBLAS batched GEMV), two copies alternating."""
@@ -544,7 +598,7 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
     """build the caches of one configuration, time args.steps decode steps, return the result dict (rank 0) or None"""
     from kvquant_amd import sharding
     total = args.steps + args.warmup
-    max_len = (args.ctx + total + 8 + 63) // 64 * 64
+    max_len = (args.ctx + total + 32 + 63) // 64 * 64             # (+ the retrieval check's and the full-model leg's tokens)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     sharded = world > 1 and not args.replicas
     streams = args.streams if args.streams > 0 else (world if sharded else 1)
@@ -675,6 +729,11 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
             res["config"]["label"] = label
         if retrieval is not None:
             res["retrieval"] = retrieval
+    if rank == 0 and with_baselines and world == 1 and not getattr(args, "no_full_model", False) and res is not None:
+        try:
+            res["full_model"] = full_model_leg(args, caches, owned, max_len, dev)
+        except Exception as e:      # (never take the headline down with it)
+            res["full_model"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del caches, qs, ks, vs
     torch.cuda.empty_cache()
     if rank == 0 and with_baselines:

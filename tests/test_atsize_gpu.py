@@ -154,38 +154,48 @@ def test_prefill_pack_8192_against_reference(ref, bits):
         assert torch.equal(mr, va.vcache)
 
 
-@pytest.mark.parametrize("bits,ctx", [(4, 131072), (3, 131072), (4, 32768)])
-def test_decode_kv_end_to_end_against_reference_pipeline(ref, bits, ctx):
-    """The one-call decode step at the BASELINE size against the pipeline assembled from the REFERENCE's own ops on the
-    same cache: its q.K^T(+RoPE, +sparse) kernel -> half(score) / sqrt(d) in fp16 -> fp32 softmax -> fp16
-    probabilities (ML:1972-1976) -> its p.V(+sparse) kernel -> half (ML:1290).  ctx cached tokens filled by the
-    fused prefill pack (the cache-fill of bench.py), then one token through decode_kv (prologue with the appends and
-    the table build at position ctx, score kernel with softmax partials, softmax finish or the fused p.V, slab
-    reduce).  North-star tolerance 1e-3."""
+@pytest.mark.parametrize("bits,ctx,sinks", [(4, 131072, 0), (3, 131072, 0), (3, 131072, 5), (4, 32768, 0)])
+def test_decode_kv_end_to_end_against_reference_pipeline(ref, bits, ctx, sinks):
+    """The one-call decode step at the BASELINE sizes against the pipeline assembled from the REFERENCE's own ops on the
+    same cache: its q.K^T(+RoPE, +sparse) kernel -> half(score) / sqrt(d) in fp16 -> [fp16 sink scores in front,
+    ML:1950-1962] -> fp32 softmax -> fp16 probabilities (ML:1972-1976) -> its p.V(+sparse) kernel -> half (ML:1290)
+    [+ the sink tokens' fp16 matmul, ML:1987-1995].  (3, 131072, 5) is BASELINE config 3: nuq3 + 1 % + 5 fp16 sink
+    tokens through decode_kv(k_sink=, v_sink=), i.e. the fused-sink launches at size.  ctx cached tokens filled by the
+    fused prefill pack (the cache-fill of bench.py), then two tokens through decode_kv.  North-star tolerance 1e-3."""
     import bench
     from kvquant_amd.cache import decode_kv
     dev = torch.device("cuda:0")
     util.sync_oracle_freqs(10000.0)
     gen = torch.Generator(device=dev).manual_seed(4321 + bits)
     max_len = (ctx + 8 + 63) // 64 * 64
-    lay = bench.Layer(bits, max_len, gen, dev, 0)
+    lay = bench.Layer(bits, max_len, gen, dev, sinks)
     lay.fill(ctx, gen, dev)
     k, v = bench.synth_tokens(2, lay.scale, lay.shift, gen, dev)
     worst = 0.0
     for step in range(2):
         q = torch.randn(H, HD, generator=gen, device=dev).half()
-        out, _ = decode_kv(lay.k, lay.v, q, k[step], v[step])
+        if sinks:
+            out, _ = decode_kv(lay.k, lay.v, q, k[step], v[step], k_sink=lay.k_sink, v_sink=lay.v_sink)
+        else:
+            out, _ = decode_kv(lay.k, lay.v, q, k[step], v[step])
         L = ctx + step + 1
-        assert lay.k.klen == L and lay.v.vlen == L
+        assert lay.k.klen == L + sinks and lay.v.vlen == L + sinks
         s = torch.zeros(1, H, L, device=dev)
         getattr(ref, "vecquant%dmatmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt2" % bits)(
             q.float().view(1, H, HD).contiguous(), lay.k.kcache, s, lay.k.lookup_table, L, lay.k.outliers,
-            lay.k.outlier_indices, 10000.0, 0)
-        p = torch.softmax(s[0].half() / math.sqrt(HD), dim=-1, dtype=torch.float32).half().float()
+            lay.k.outlier_indices, 10000.0, sinks)
+        w = s[0].half() / math.sqrt(HD)
+        if sinks:
+            w = torch.cat(((torch.matmul(q.view(H, 1, HD), lay.k_sink) / math.sqrt(HD))[:, 0, :], w), dim=-1)
+        p = torch.softmax(w, dim=-1, dtype=torch.float32).half()
         o = torch.zeros(1, H, HD, device=dev)
         getattr(ref, "vecquant%dmatmul_nuq_perchannel_transposed_mha_batched_fused_opt2" % bits)(
-            p.view(1, H, L).contiguous(), lay.v.vcache, o, lay.v.lookup_table, L, lay.v.outliers, lay.v.outlier_indices)
-        err = util.rel_err(out.float().reshape(1, -1), o.half().float().reshape(1, -1))
+            p[:, sinks:].float().reshape(1, H, L).contiguous(), lay.v.vcache, o, lay.v.lookup_table, L, lay.v.outliers,
+            lay.v.outlier_indices)
+        o = o[0].half()
+        if sinks:
+            o = o + torch.matmul(p[:, :sinks].view(H, 1, sinks), lay.v_sink)[:, 0, :]
+        err = util.rel_err(out.float().reshape(1, -1), o.float().reshape(1, -1))
         worst = max(worst, err)
-    print("decode_kv end to end, bits=%d ctx=%d: |out - reference pipeline| %.2e" % (bits, ctx, worst))
+    print("decode_kv end to end, bits=%d ctx=%d sinks=%d: |out - reference pipeline| %.2e" % (bits, ctx, sinks, worst))
     assert worst < TOL
