@@ -191,4 +191,13 @@ __device__ __forceinline__ void vm_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// p.V: the row unit a lane owns (one packed word-row = 8 / 16 channels at 4 / 2 bit, three rows = 32 channels at 3 bit)
+template <int BITS>
+struct Unit {
+  static constexpr int kWords = BITS == 3 ? 3 : 1;                   // word-rows per unit
+  static constexpr int kCh = BITS == 4 ? 8 : (BITS == 3 ? 32 : 16);  // channels per unit
+  static constexpr int kPerHead = kHeadDim / kCh;
+  static constexpr int kBatch = BITS == 3 ? 8 : 16;  // tokens per register batch (16-byte loads)
+};
+
 }  // namespace kvq

@@ -36,297 +36,21 @@
 // + 4*H (probabilities) (+ 8*n_out sparse).
 #include "kvq_common.h"
 #include "kvq_host.h"
-#include "kvq_mix_v_rows.h"
+#include "kvq_mix_v_stage.h"
 #include "kvq_mix_lut.h"
 
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
-#ifndef KVQ_V_WGS
-#define KVQ_V_WGS 512
-#endif
-#ifndef KVQ_V_NOSP
-#define KVQ_V_NOSP 0   // experiment: LDS without the sparse-phase buffers (compile-only occupancy probes)
-#endif
-#ifndef KVQ_V_CT16
-#define KVQ_V_CT16 0
-#endif
-#ifndef KVQ_V_WAVES
-#define KVQ_V_WAVES 4    // waves per SIMD the register allocation aims at
-#endif
-#ifndef KVQ_V_MERGE_PARTS
-#define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles (64K tokens) the p.V workgroups merge the softmax partials themselves (beyond: 6.09 vs 6.01 ms/step at 128K)
-#endif
-#ifndef KVQ_V_RB
-#define KVQ_V_RB 24
-#endif
-#ifndef KVQ_V_PRIO
-#define KVQ_V_PRIO 0    // experiment (measured neutral): wave priority (s_setprio): 1 = high outside the look-up loop (chunk hand-over, sparse phase), low inside;
-#endif                  //  2 = the two workgroups of a CU take turns by chunk parity; 3 = both
-#ifndef KVQ_TRACE
-#define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the chunk loop (tools/dbg/trace_v.py)
-#endif
-#ifndef KVQ_PAD_LDS
-#define KVQ_PAD_LDS 0   // development: extra LDS per workgroup (occupancy experiments)
-#endif
-#ifndef KVQ_V_DBG
-#define KVQ_V_DBG 0   // development ablations (-DKVQ_V_DBG=n): 1 skip the math, 2 skip the DMA, 4 DMA from an L2-resident source
-#endif
+#define KVQ_V_WGS 512           // workgroups the plan aims at (2 per CU)
+#define KVQ_V_WAVES 4           // waves per SIMD the register allocation aims at
+#define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles (64K tokens) the p.V workgroups merge the partials themselves
+#define KVQ_V_RB 24             // outlier phase: entries per lane and round
+// (the experiment switches of rounds 2-3 -- wave priorities, 16-token chunks at 4 bit, the C++ look-up loops next to the
+//  hand-scheduled ones, DMA in one burst, the development ablations -- were measured neutral or slower and are gone;
+//  DESIGN.md 3 keeps the numbers)
 
 namespace kvq {
-
-template <int BITS>
-struct VCfg {
-  static constexpr int N = Fmt<BITS>::kN;
-  static constexpr int WORDS = Unit<BITS>::kWords;     // word-rows per unit
-  static constexpr int CH = Unit<BITS>::kCh;           // channels per unit
-  static constexpr int UPH = kHeadDim / CH;            // units per head
-  static constexpr int NT = 512;                       // threads per workgroup
-  static constexpr int UW = BITS == 3 ? 128 : 256;     // units per workgroup
-  // 3 bit: a unit is 32 channels in 3 word-rows; two lanes ("halves", wave-uniform: lanes [0,UW) / [UW,2UW) of a
-  // slot) read the same three rows and decode 16 channels each -- 32 accumulators in one lane do not fit the
-  // 128-VGPR budget next to the look-ups in flight, and a spill inside the chunk loop makes hipcc drain the
-  // DMAs just issued
-  static constexpr int HALVES = BITS == 3 ? 2 : 1;
-  static constexpr int CHL = CH / HALVES;              // channels per lane
-  static constexpr int SLOTS = NT / (UW * HALVES);     // token slots
-  static constexpr int CT = (BITS == 4 && !KVQ_V_CT16) ? 32 : 16;       // tokens per chunk (2 bit: 32 needs ~200 VGPRs as unrolled)
-  static constexpr int QR = CT / 4;                    // 16-byte quads per tile row
-  static constexpr int SH = CT == 32 ? 1 : 2;          // log2(tile rows per 256 B)
-  static constexpr int ROWS = UW * WORDS;              // tile rows
-  static constexpr int ROWB = CT * 4;                  // tile row bytes
-  static constexpr int TILE_B = ROWS * ROWB;
-  static constexpr int HW = UW / UPH;                  // heads per workgroup
-  static constexpr int LUT_B = CT * N * 4;
-  static constexpr int P_B = HW * CT * 4;
-  static constexpr int QPL = QR / SLOTS;               // quads per lane per chunk
-  // LDS layout of the two pipeline stages: the small arrays first, so that every look-up address of either stage is
-  // an instruction immediate (16 bits) on top of a byte-sized register value: [rows 0][rows 1][p 0][p 1][p 2][tile 0][tile 1]
-  // (p 2: the fused-softmax mode converts scores one chunk ahead of the one being read)
-  static constexpr int NPB = 3;
-  static constexpr int lut_off(int st) { return st * LUT_B; }
-  static constexpr int p_off(int st) { return 2 * LUT_B + st * P_B; }
-  static constexpr int tile_off(int st) { return 2 * LUT_B + NPB * P_B + st * TILE_B; }
-  static constexpr int STAGES_B = 2 * LUT_B + NPB * P_B + 2 * TILE_B;
-  static constexpr int RED_B = NT * CHL * 4;           // slot reduction (aliases the stages)
-  // sparse phase after the loop (aliases the stages): staged probabilities of the workgroup's token share
-  // (37 KB: 288 tokens x 32 heads, odd row stride) + 32 KB of 64-bit accumulators (4096 channels in one pass)
-  static constexpr int SP_P_B = 37888;
-  static constexpr int SP_B = SP_P_B + 32768;
-  static constexpr int SMEM_0 = (STAGES_B > RED_B ? STAGES_B : RED_B);
-  static constexpr int SMEM_B = KVQ_V_NOSP ? SMEM_0 : (SMEM_0 > SP_B ? SMEM_0 : SP_B);
-  static constexpr int MZ_HEADS = 128;                 // fused softmax: (max, normaliser) of every head, behind everything else
-  static constexpr int MZ_B = MZ_HEADS * 8;
-  static_assert(P_B / 4 == NT, "the fused softmax converts one score per lane per chunk");
-  static_assert(QR % SLOTS == 0, "slots must split the chunk's quads");
-};
-
-struct MixArgs {
-  const float *p;          // [q_len][H][L]
-  const uint32_t *mat;     // [rows][max_len]
-  const float *lut_rows;   // [max_len][N]
-  const float *outliers;
-  const int32_t *idx;
-  float *partial;          // [n_ranges][q_len][C]
-  int H;
-  int q_len;
-  int64_t L;
-  int64_t max_len;
-  int64_t tr;              // tokens per range (multiple of CT)
-  int groups;              // unit groups (workgroups per range)
-  int n_units;
-  int n_out;
-  uint32_t n_out_magic;    // ceil(2^32 / n_out)
-  // FUSED softmax (decode, q_len = 1): `p` is unused; the kernel reads the RAW scores and converts them to
-  // probabilities on the way (exactly the arithmetic of kvq_softmax_finish: half(expf(half(half(s) * inv) - M) / Z))
-  const float *scores;     // [H][L]
-  const float *mz;         // [H][2]: (max, normaliser) of every row, merged from the partials by softmax_merge_kernel,
-                           // or null: few partials (short caches), every workgroup merges them itself (one launch less)
-  const float *parts;      // [H][n_parts][2]
-  int n_parts;
-  const __half *sink;      // [H][n_sink] or null
-  __half *sink_probs;
-  int n_sink;
-  const __half *v_sink;    // [H][n_sink][128] or null: the sink tokens' output goes to sink_out (= mul, which the reduce accumulates onto)
-  float *sink_out;
-  float inv;
-#if KVQ_TRACE
-  unsigned long long *trace;   // development: [block][wave][chunk][8]
-#endif
-};
-
-// Per-lane constants of the chunk DMA.  Every tile DMA instruction of a wave moves 64/QR consecutive
-// tile rows; instruction k of a wave is rows 64/QR*8*k further down, which is a wave-uniform pointer
-// increment, so ONE 32-bit lane offset serves all of a wave's tile instructions.
-struct DmaLane {
-  uint32_t tile_row;   // first tile row of this lane (instruction k adds k * rows_per_round)
-  uint32_t tile_q4;    // token offset (4*source quad) inside the chunk
-  uint32_t lut_tok;    // token (within chunk) whose codebook row this lane fetches
-  uint32_t lut_sub;    // float offset inside that row
-  uint32_t p_head;     // head (relative to h0) / token (within chunk) of the probability this lane fetches
-  uint32_t p_tok;
-};
-
-template <int BITS>
-__device__ __forceinline__ DmaLane make_dma_lane() {
-  using Cfg = VCfg<BITS>;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  DmaLane d;
-  const int s = wave * 64 + lane;              // slot of the wave's first tile instruction
-  const int r = s / Cfg::QR;
-  const int pos = s % Cfg::QR;
-  d.tile_row = r;
-  d.tile_q4 = 4 * ((pos - ((r >> Cfg::SH) & (Cfg::QR - 1))) & (Cfg::QR - 1));
-  // codebook rows: LDS row index pidx holds token tl with pidx = (qq*4+e)*SLOTS + slot,
-  // tl = (slot*QPL+qq)*4+e: the rows the slots decode in one step sit next to each other
-  const int pidx = (s * 4) / Cfg::N;
-  const int qe = pidx / Cfg::SLOTS, slp = pidx % Cfg::SLOTS;
-  d.lut_tok = (slp * Cfg::QPL + qe / 4) * 4 + qe % 4;
-  d.lut_sub = (s * 4) % Cfg::N;
-  d.p_head = s / Cfg::CT;
-  d.p_tok = s % Cfg::CT;
-  return d;
-}
-
-// probabilities (or, fused softmax: raw scores) of the workgroup's heads for tokens [c0, c0+CT) -> LDS `pbuf`
-// ([HW][CT] floats), 4 B per lane
-template <int BITS>
-__device__ __forceinline__ void issue_p(const float *src, const MixArgs &a, const DmaLane &d, uint32_t pbuf, int64_t c0,
-                                        int h0, int b) {
-  using Cfg = VCfg<BITS>;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int NW = Cfg::NT / 64;
-  constexpr int N_P = Cfg::P_B / 256;
-  constexpr int K_P = (N_P + NW - 1) / NW;
-  const int lim_L = (int)(a.L - c0);           // tokens from the chunk start to the end of the cache
-  const float *gbase = src + ((int64_t)b * a.H + h0) * a.L + c0;
-  const uint32_t toff = (uint32_t)(lim_L <= 0 ? 0 : ((int)d.p_tok < lim_L ? (int)d.p_tok : lim_L - 1));
-  if (lim_L <= 0) gbase = src + ((int64_t)b * a.H + h0) * a.L + a.L - 1;
-#pragma unroll
-  for (int k = 0; k < K_P; k++) {
-    const int j = wave + k * NW;
-    if (j < N_P) {
-      int hr = d.p_head + k * NW * (64 / Cfg::CT);
-      if (h0 + hr >= a.H) hr = a.H - 1 - h0;
-      const uint32_t voff = ((uint32_t)hr * (uint32_t)a.L + toff) * 4u;
-      dma4(gbase, voff, pbuf + j * 256);
-    }
-  }
-}
-
-// issue the DMA of one chunk (tokens [c0, c0+CT)) into stage `buf`.  (Issued in one burst right after the chunk
-// barrier, the 42 pieces of the workgroup's 8 waves queue up in the CU's memory front end and cost every wave ~1300
-// cycles per chunk by s_memtime -- but spreading them over the math was measured neutral, 88 vs 88 us: the queueing
-// is hidden by the other waves.)
-template <int BITS>
-__device__ __forceinline__ void issue_chunk(const MixArgs &a, const DmaLane &d, uint32_t lds0, int stage, int64_t c0,
-                                            int row_base, int n_rows_valid, int h0, int b, bool with_p = true) {
-  using Cfg = VCfg<BITS>;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int NW = Cfg::NT / 64;
-  constexpr int RPI = 64 / Cfg::QR;                  // tile rows per DMA instruction
-  constexpr int N_TILE = Cfg::TILE_B / 1024;
-  constexpr int K_TILE = (N_TILE + NW - 1) / NW;     // tile instructions per wave
-  constexpr int LUT_SLOTS = Cfg::LUT_B / 16;
-  // ---- packed rows: uniform base per instruction, ONE 32-bit lane offset (bytes) for all of them
-  // (token clamps in 32-bit arithmetic relative to the chunk: wave-uniform 64-bit limits, 32-bit lane values --
-  // 64-bit per-lane compares cost VGPR pairs, and a spill in here makes hipcc drain the DMAs just issued)
-  const int lim_len = (int)(a.max_len - c0);   // tokens from the chunk start to the end of the rows (multiple of 4, >= 4)
-  {
-    const uint32_t *gbase = a.mat + (int64_t)row_base * a.max_len + c0;
-    const int tq = (int)d.tile_q4;
-    const uint32_t toff = (uint32_t)(tq + 4 > lim_len ? lim_len - 4 : tq);
-#pragma unroll
-    for (int k = 0; k < K_TILE; k++) {
-      const int j = wave + k * NW;
-      if (j < N_TILE) {
-        int r = d.tile_row + k * NW * RPI;
-        if (r >= n_rows_valid) r = n_rows_valid - 1;
-        const uint32_t voff = ((uint32_t)r * (uint32_t)a.max_len + toff) * 4u;   // < 2^32 (checked by the host)
-        dma16(gbase, voff, lds0 + Cfg::tile_off(stage) + j * 1024);
-      }
-    }
-  }
-  // ---- codebook rows of the chunk
-  if ((int)threadIdx.x < LUT_SLOTS) {   // wave-granular: LUT_SLOTS is a multiple of 64 or < 64
-    const int tr2 = (int)d.lut_tok < lim_len ? (int)d.lut_tok : lim_len - 1;
-    const float *gbase = a.lut_rows + c0 * Cfg::N;
-    const uint32_t voff = ((uint32_t)tr2 * Cfg::N + d.lut_sub) * 4u;
-    dma16(gbase, voff, lds0 + Cfg::lut_off(stage) + wave * 1024);
-  }
-  if (with_p) issue_p<BITS>(a.p, a, d, lds0 + Cfg::p_off(stage), c0, h0, b);
-}
-
-
-// The common case of issue_chunk -- a chunk that lies entirely inside the rows and the cache, a full unit group --
-// needs no clamps: the per-lane part of every source address is a constant of the kernel (three VGPRs), everything
-// that changes with the chunk or the piece is in the wave-uniform base.  PART q in [0, QPL): the tile pieces k with
-// k % QPL == q, and with q == 0 the codebook rows and the probabilities: the hand-scheduled loop issues one part per
-// quad, between its look-ups.  (Issued in one burst after the chunk barrier, the 42 pieces of a workgroup queue up in
-// the CU's memory front end -- 64 B/clk -- and every wave sits ~1500 cycles per chunk in the issue, 20 % of the
-// kernel by s_memtime once the look-up loop itself is fast.)
-struct DmaFast {
-  uint32_t tile, lut, p;   // byte offsets
-};
-
-template <int BITS>
-__device__ __forceinline__ DmaFast make_dma_fast(const MixArgs &a, const DmaLane &d) {
-  using Cfg = VCfg<BITS>;
-  DmaFast f;
-  f.tile = (d.tile_row * (uint32_t)a.max_len + d.tile_q4) * 4u;
-  f.lut = (d.lut_tok * Cfg::N + d.lut_sub) * 4u;
-  f.p = (d.p_head * (uint32_t)a.L + d.p_tok) * 4u;
-  return f;
-}
-
-template <int BITS, int PART>
-__device__ __forceinline__ void issue_fast(const MixArgs &a, const DmaFast &f, uint32_t lds0, int stage, int pstage,
-                                           const float *psrc, int64_t c0, int64_t pc0, int row_base, int h0, int b) {
-  using Cfg = VCfg<BITS>;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int NW = Cfg::NT / 64;
-  constexpr int RPI = 64 / Cfg::QR;
-  constexpr int N_TILE = Cfg::TILE_B / 1024;
-  constexpr int K_TILE = (N_TILE + NW - 1) / NW;
-  constexpr int LUT_SLOTS = Cfg::LUT_B / 16;
-  constexpr int N_P = Cfg::P_B / 256;
-  constexpr int K_P = (N_P + NW - 1) / NW;
-#pragma unroll
-  for (int k = 0; k < K_TILE; k++) {
-    if (k % Cfg::QPL != PART) continue;
-    const int j = wave + k * NW;
-    if (j < N_TILE)
-      dma16(a.mat + (int64_t)(row_base + k * NW * RPI) * a.max_len + c0, f.tile, lds0 + Cfg::tile_off(stage) + j * 1024);
-  }
-  if (PART != 0) return;
-  if ((int)threadIdx.x < LUT_SLOTS) dma16(a.lut_rows + c0 * Cfg::N, f.lut, lds0 + Cfg::lut_off(stage) + wave * 1024);
-#pragma unroll
-  for (int k = 0; k < K_P; k++) {
-    const int j = wave + k * NW;
-    if (j < N_P)
-      dma4(psrc + ((int64_t)b * a.H + h0 + k * NW * (64 / Cfg::CT)) * a.L + pc0, f.p, lds0 + Cfg::p_off(pstage) + j * 256);
-  }
-}
-
-#ifndef KVQ_V_SPREAD
-#define KVQ_V_SPREAD 1   // hand-scheduled loop: issue the next chunk's DMA a quad's share at a time (0: one burst after the barrier)
-#endif
-#ifndef KVQ_V_ASM
-#define KVQ_V_ASM 1   // 4 bit: the chunk's look-up loop as hand-scheduled instruction groups (0: what hipcc makes of the C++)
-#endif
-
-template <int BITS, int I, int WORDS>
-__device__ __forceinline__ unsigned vcode(const uint32_t (&w)[WORDS]) {
-  if constexpr (BITS == 3) return code_of<3, I>(w);
-  else if constexpr (BITS == 4) return (w[0] >> (4 * I)) & 0xfu;
-  else return (w[0] >> (2 * I)) & 0x3u;
-}
-
-// 2^(d log2 e): the weights that merge the (max, sum) partials of a softmax row (as kvq_softmax.hip does)
-__device__ __forceinline__ float mz_w(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
-// raw score -> fp16-rounded probability, the arithmetic of kvq_softmax_finish (modeling_llama.py:873-874, 1972-1976)
-__device__ __forceinline__ float prob_of(float raw, float inv, float M, float rZ) { return prob_fp16(scaled(raw, inv), M, rZ); }
 
 // FUSED: the second softmax pass (kvq_softmax_finish) happens inside this kernel -- the workgroups merge the
 // (max, sum) partials of the score kernel themselves and convert raw scores to probabilities in LDS, one chunk
@@ -336,12 +60,7 @@ template <int BITS, bool FUSED>
 __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   using Cfg = VCfg<BITS>;
   constexpr int N = Cfg::N, CH = Cfg::CH, WORDS = Cfg::WORDS, CT = Cfg::CT, CHL = Cfg::CHL;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B + (FUSED ? Cfg::MZ_B : 0) + KVQ_PAD_LDS];  // static: LDS offsets fold into ds immediates
-  unsigned char *stage0 = smem;
-
-#if KVQ_V_PRIO & 1
-  __builtin_amdgcn_s_setprio(3);         // (everything outside the look-up loop is a latency chain)
-#endif
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM_B + (FUSED ? Cfg::MZ_B : 0)];  // static: LDS offsets fold into ds immediates
   const int tid = threadIdx.x;
   const int ul = tid % Cfg::UW;          // unit within the workgroup
   const int hf = __builtin_amdgcn_readfirstlane((tid / Cfg::UW) % Cfg::HALVES);   // which half of the unit's channels
@@ -381,10 +100,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   // order, one's latency-bound phase hides behind the other's look-ups (nuq3 p.V + reduce at 128K: 84 us alternating,
   // 91 us with every phase at the end).  The groups of a range (blocks 8 apart) have the same parity: they read the
   // range's entries at about the same time.
-#ifndef KVQ_V_SPFIRST
-#define KVQ_V_SPFIRST 1   // 0: always after the loop; 1: odd workgroups first
-#endif
-  const bool sparse_first = !FUSED && sparse && KVQ_V_SPFIRST && (blockIdx.x & 1);
+  const bool sparse_first = !FUSED && sparse && (blockIdx.x & 1);
   if (!sparse_first) issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
   const float2 *mz = reinterpret_cast<const float2 *>(smem + Cfg::SMEM_B);   // FUSED: (max, normaliser) per head
   float myM = 0.f, myZ = 1.f;                                                  // ... of the head this lane converts for
@@ -571,7 +287,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
             for (int m = 0; m < 5; m++) {
               const int hh = hb + wv + 8 * k, tl = ln + 64 * m;
               if (hh < HWv && tl < ns)
-                pl[hh * nsp + tl] = (FUSED && !(KVQ_V_DBG & 128)) ? prob_of(v[k][m], a.inv, mz[h0 + hh].x, mz[h0 + hh].y) : v[k][m];
+                pl[hh * nsp + tl] = FUSED ? prob_of(v[k][m], a.inv, mz[h0 + hh].x, mz[h0 + hh].y) : v[k][m];
             }
         }
       }
@@ -660,31 +376,22 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #pragma unroll
   for (int i = 0; i < CHL; i++) acc[i] = 0.f;
 
-  // per-lane constant pieces of the LDS addresses
-  int rowoff[WORDS], rot[WORDS];
-#pragma unroll
-  for (int wi = 0; wi < WORDS; wi++) {
-    const int r = ul * WORDS + wi;
-    rowoff[wi] = r * Cfg::ROWB;
-    rot[wi] = (r >> Cfg::SH) & (Cfg::QR - 1);
-  }
 
   // slot pattern OR-ed into the pre-masked nibble bytes (4-bit fast path): byte = slot*64 + code*4
   const uint32_t slotpat = (uint32_t)sl * 0x40404040u;
 
   // hand-scheduled loops (3 / 4 bit): the lane's LDS addresses inside a stage do not change with the chunk
-  constexpr bool ASM_LOOP = KVQ_V_ASM;
   uint32_t taddr[Cfg::QPL][WORDS];   // its 16-byte quads of the tile
   uint32_t paddr = 0;                // the probabilities of its head for its slot's tokens
-  if constexpr (ASM_LOOP) {
-    if (lds0 != 0) __builtin_trap();   // (the instruction immediates below assume the one static LDS array at 0)
+  if (lds0 != 0) __builtin_trap();   // (the instruction immediates below assume the one static LDS array at 0)
 #pragma unroll
-    for (int qq = 0; qq < Cfg::QPL; qq++)
+  for (int qq = 0; qq < Cfg::QPL; qq++)
 #pragma unroll
-      for (int wi = 0; wi < WORDS; wi++)
-        taddr[qq][wi] = (uint32_t)(rowoff[wi] + (((sl * Cfg::QPL + qq + rot[wi]) & (Cfg::QR - 1)) << 4));
-    paddr = (uint32_t)((hl * CT + sl * Cfg::QPL * 4) * 4);
-  }
+    for (int wi = 0; wi < WORDS; wi++) {
+      const int r = ul * WORDS + wi, rot = (r >> Cfg::SH) & (Cfg::QR - 1);     // (tile row, its quad rotation)
+      taddr[qq][wi] = (uint32_t)(r * Cfg::ROWB + (((sl * Cfg::QPL + qq + rot) & (Cfg::QR - 1)) << 4));
+    }
+  paddr = (uint32_t)((hl * CT + sl * Cfg::QPL * 4) * 4);
 
   auto chunk = [&](auto STAGE, int ci) {
     constexpr int stage = decltype(STAGE)::value;
@@ -702,24 +409,24 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #if KVQ_TRACE
     stamp(1);
 #endif
-    if (!(KVQ_V_DBG & 32)) __syncthreads();   // ... and everybody else's; the other stage is free again
+    __syncthreads();   // ... and everybody else's; the other stage is free again
 #if KVQ_TRACE
     stamp(2);
 #endif
-    const int64_t cn0 = (KVQ_V_DBG & 4) ? t0 : c0 + CT;                   // start of the next chunk
-    const bool more = ci + 1 < n_chunks && (!(KVQ_V_DBG & 2) || a.q_len > 1000);
+    const int64_t cn0 = c0 + CT;                   // start of the next chunk
+    const bool more = ci + 1 < n_chunks;
     // FUSED: the scores travel one chunk further ahead than the rows (chunk ci+2 -> p buffer (ci+2) % 3)
     const int pcur = FUSED ? ci % 3 : stage;
     const int pnext = FUSED ? (ci + 2) % 3 : 1 - stage;
     const int64_t pc0 = FUSED ? cn0 + CT : cn0;
-    const bool spread = ASM_LOOP && KVQ_V_SPREAD && pc0 <= fast_end;   // (wave-uniform)
+    const bool spread = pc0 <= fast_end;   // (wave-uniform)
     if (more && !spread) {
       issue_chunk<BITS>(a, dl, lds0, 1 - stage, cn0, row_base, n_rows_valid, h0, b, !FUSED);
       if (FUSED && ci + 2 < n_chunks) issue_p<BITS>(a.scores, a, dl, lds0 + Cfg::p_off(pnext), pc0, h0, b);
     }
     // the next chunk's scores landed with this chunk's rows (issued one chunk earlier): convert them now -- in the
     // hand-scheduled loop the LDS read is issued here and the value is used two quads later, behind the look-ups
-    constexpr bool CONV_IN_LOOP = FUSED && BITS == 4 && KVQ_V_ASM && Cfg::QPL >= 3;
+    constexpr bool CONV_IN_LOOP = FUSED && BITS == 4 && Cfg::QPL >= 3;
     float raw_next = 0.f;
     const uint32_t conv_addr = (uint32_t)(tid * 4 + ((ci + 1) % 3) * Cfg::P_B);
     if constexpr (CONV_IN_LOOP) {
@@ -730,8 +437,6 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #if KVQ_TRACE
     stamp(3);
 #endif
-    const unsigned char *tile = smem + Cfg::tile_off(stage);
-    const unsigned char *lutb = smem + Cfg::lut_off(stage);
     float *pb = reinterpret_cast<float *>(smem + Cfg::p_off(pcur));
     const int rem = (int)(t1 - c0);       // tokens of this range left in the chunk
     if (!FUSED && rem < CT) {             // ragged last chunk: zero the probabilities past the end once
@@ -739,17 +444,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
         if (i % CT >= rem) pb[i] = 0.f;
       __syncthreads();
     }
-    if (KVQ_V_DBG & 1) return;
-#if KVQ_V_PRIO
-    {
-      const int turn = (KVQ_V_PRIO & 2) ? ((ci + ((int)blockIdx.x >= (int)gridDim.x / 2 ? 1 : 0)) & 1) : 0;
-      __builtin_amdgcn_sched_barrier(0);
-      if (turn) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
-    if constexpr (BITS == 4 && KVQ_V_ASM) {
+    if constexpr (BITS == 4) {
       constexpr int S0 = Cfg::tile_off(stage);                  // tile
       constexpr int L0 = Cfg::lut_off(stage);                   // codebook rows (row (qq*4+e)*SLOTS + slot)
       constexpr int P0 = Cfg::p_off(0);                         // probabilities (buffer offset in the address register)
@@ -768,7 +463,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
         if constexpr (CONV_IN_LOOP && qq == 1) asm volatile("" : "+v"(raw_next));   // (landed: everything older than this wait has)
         if constexpr (CONV_IN_LOOP && qq == 2) {
           if (more) {
-            float pr = (KVQ_V_DBG & 64) ? raw_next : ((cn0 + (tid % CT) < t1) ? prob_of(raw_next, a.inv, myM, myZ) : 0.f);
+            float pr = (cn0 + (tid % CT) < t1) ? prob_of(raw_next, a.inv, myM, myZ) : 0.f;
             asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(conv_addr), "v"(pr), "n"(Cfg::p_off(0)) : "memory");
           }
         }
@@ -795,7 +490,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #endif
       return;
     }
-    if constexpr (BITS == 3 && KVQ_V_ASM) {
+    if constexpr (BITS == 3) {
       // per token: two groups of 8 look-ups (codes 0..7 and 8..15 of the lane's half); the groups of token t+1 are in
       // flight while token t is accumulated, as in the 4-bit loop
       constexpr int S0 = Cfg::tile_off(stage);
@@ -858,7 +553,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #endif
       return;
     }
-    if constexpr (BITS == 2 && KVQ_V_ASM) {
+    if constexpr (BITS == 2) {
       // as the 3-bit loop: two groups of 8 look-ups per token (channels 0..7 and 8..15 of the word)
       constexpr int S0 = Cfg::tile_off(stage);
       constexpr int L0 = Cfg::lut_off(stage);
@@ -910,100 +605,10 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #endif
       return;
     }
-    int rotv[WORDS];
-#pragma unroll
-    for (int wi = 0; wi < WORDS; wi++) {
-      rotv[wi] = rot[wi];
-      asm volatile("" : "+v"(rotv[wi]));   // recompute the tile addresses per chunk (else hoisted and spilled)
-    }
-    static_for<0, Cfg::QPL>([&](auto QQ) {
-      constexpr int qq = decltype(QQ)::value;
-      const int q = sl * Cfg::QPL + qq;
-      uint4 wq[WORDS];
-#pragma unroll
-      for (int wi = 0; wi < WORDS; wi++) {
-        if (KVQ_V_DBG & 16) {
-          wq[wi] = make_uint4(rotv[wi] * 0x9E3779B1u, rowoff[wi] * 0x85EBCA6Bu, tid * 0xC2B2AE35u, (tid + q) * 0x27D4EB2Fu);
-          asm volatile("" : "+v"(wq[wi].x), "+v"(wq[wi].y), "+v"(wq[wi].z), "+v"(wq[wi].w));
-        } else {
-          wq[wi] = *reinterpret_cast<const uint4 *>(tile + rowoff[wi] + (((q + rotv[wi]) & (Cfg::QR - 1)) << 4));
-        }
-      }
-      float4 p4;
-      if (KVQ_V_DBG & 8) {
-        p4 = make_float4(0.5f, 0.25f, 0.125f, 0.0625f);
-        asm volatile("" : "+v"(p4.x), "+v"(p4.y), "+v"(p4.z), "+v"(p4.w));
-      } else {
-        p4 = *reinterpret_cast<const float4 *>(pb + hl * CT + q * 4);
-      }
-      static_for<0, 4>([&](auto E) {
-        constexpr int e = decltype(E)::value;
-        uint32_t w[WORDS];
-#pragma unroll
-        for (int wi = 0; wi < WORDS; wi++)
-          w[wi] = e == 0 ? wq[wi].x : (e == 1 ? wq[wi].y : (e == 2 ? wq[wi].z : wq[wi].w));
-        const float pt = e == 0 ? p4.x : (e == 1 ? p4.y : (e == 2 ? p4.z : p4.w));
-        if constexpr (BITS == 4) {
-          // even / odd nibbles as bytes holding code*4 (+ slot*64): one v_bfe_u32 per code gives the
-          // complete variable part of the LDS address, everything else is an instruction immediate
-          const uint32_t we = ((w[0] << 2) & 0x3C3C3C3Cu) | slotpat;
-          const uint32_t wo = ((w[0] >> 2) & 0x3C3C3C3Cu) | slotpat;
-          const unsigned char *row = lutb + (qq * 4 + e) * Cfg::SLOTS * N * 4;
-          static_for<0, 8>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            const uint32_t src = (i & 1) ? wo : we;
-            const uint32_t off = (src >> (8 * (i / 2))) & 0xffu;
-            acc[i] = fmaf(*reinterpret_cast<const float *>(row + off), pt, acc[i]);
-          });
-        } else if constexpr (BITS == 2) {
-          // same idea at 2 bit: byte b of pre-masked word k holds code*4 (+ slot*16) of channel 4b + k
-          const uint32_t sp2 = (uint32_t)sl * 0x10101010u;
-          const uint32_t pk[4] = {((w[0] << 2) & 0x0C0C0C0Cu) | sp2, (w[0] & 0x0C0C0C0Cu) | sp2,
-                                  ((w[0] >> 2) & 0x0C0C0C0Cu) | sp2, ((w[0] >> 4) & 0x0C0C0C0Cu) | sp2};
-          const unsigned char *row = lutb + (qq * 4 + e) * Cfg::SLOTS * N * 4;
-          static_for<0, 2>([&](auto HF) {          // 8 look-ups in flight at a time
-            static_for<0, 8>([&](auto I) {
-              constexpr int i = decltype(HF)::value * 8 + decltype(I)::value;
-              const uint32_t off = (pk[i & 3] >> (8 * (i / 4))) & 0xffu;
-              acc[i] = fmaf(*reinterpret_cast<const float *>(row + off), pt, acc[i]);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        } else {
-          const float *tab = reinterpret_cast<const float *>(lutb) + ((qq * 4 + e) * Cfg::SLOTS + sl) * N;
-          static_for<0, Cfg::HALVES>([&](auto HF) {      // (wave-uniform branch: the code positions are compile-time)
-            if (hf == decltype(HF)::value)
-              static_for<0, CHL>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                acc[i] = fmaf(tab[vcode<BITS, decltype(HF)::value * CHL + i, WORDS>(w)], pt, acc[i]);
-              });
-          });
-        }
-        if constexpr (CHL > 8 || (e & 1))
-          __builtin_amdgcn_sched_barrier(0);   // 16 look-ups (two 4-bit tokens / one 2-bit token) or one 3-bit token's 32 in
-                                               // flight at a time (VGPR budget)
-      });
-    });
-#if KVQ_TRACE
-    asm volatile("" :: "v"(acc[0]));
-    stamp(4);
-#endif
   };
-  auto hand_over = [&]() {
-#if KVQ_V_PRIO & 1
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(3);       // chunk hand-over (wait, barrier, DMA issue): latency, not throughput
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-  };
-  hand_over();
   for (int ci = 0; ci < n_chunks; ci += 2) {
     chunk(std::integral_constant<int, 0>{}, ci);
-    hand_over();
-    if (ci + 1 < n_chunks) {
-      chunk(std::integral_constant<int, 1>{}, ci + 1);
-      hand_over();
-    }
+    if (ci + 1 < n_chunks) chunk(std::integral_constant<int, 1>{}, ci + 1);
   }
 
   // ---- sum the token slots through LDS (aliases the pipeline stages)
@@ -1224,16 +829,6 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
 
 constexpr int kMergeInKernelParts = KVQ_V_MERGE_PARTS;   // up to this many score tiles (256 tokens each): the p.V workgroups merge the softmax partials themselves
 
-struct FusedSoftmax {
-  const float *scores, *parts;
-  int n_parts;
-  float inv;
-  const __half *sink;
-  __half *sink_probs;
-  int n_sink;
-  const __half *v_sink;
-};
-
 template <int BITS>
 static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, const FusedSoftmax *fs = nullptr) {
   using Cfg = VCfg<BITS>;
@@ -1289,102 +884,10 @@ int launch_softmax_merge(const float *parts, int n_parts, const void *sink, void
 }
 int mix_merge_in_kernel_parts() { return kMergeInKernelParts; }
 
-static size_t ws_bytes(int bits, int q_len, int H, int64_t L) {
-  size_t a = bits == 4 ? plan_mix<4>(q_len, H, L).bytes : (bits == 3 ? plan_mix<3>(q_len, H, L).bytes : plan_mix<2>(q_len, H, L).bytes);
-  size_t b = plan_mix_rows(bits, q_len, H, L, true).bytes;
-  return a > b ? a : b;
+size_t mix_plan_bytes(int bits, int q_len, int H, int64_t L) {
+  return bits == 4 ? plan_mix<4>(q_len, H, L).bytes : (bits == 3 ? plan_mix<3>(q_len, H, L).bytes : plan_mix<2>(q_len, H, L).bytes);
 }
-
-}  // namespace kvq
-
-using namespace kvq;
-
-extern "C" {
-
-size_t kvq_mix_v_workspace_bytes(int bits, int q_len, int H, int hd, int64_t L) {
-  if (bits < 2 || bits > 4 || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0) return 0;
-  return ws_bytes(bits, q_len, H, L > 0 ? L : 1);
-}
-
-static bool mix_fast_shape(const int32_t *mat, const float *lut_rows, int H, int hd, int64_t L, int64_t max_len, int bits) {
-  return (max_len % 4 == 0) && (max_len >= 4) && ((int64_t)H * (hd / 32 * bits) * max_len < (1ll << 31)) &&
-         ((reinterpret_cast<uintptr_t>(mat) | reinterpret_cast<uintptr_t>(lut_rows)) % 16 == 0);
-}
-
-// p: the probabilities, or with `fs` the raw scores (fast shapes only)
-static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int32_t *mat, float *mul, const float *lut_rows,
-                     int q_len, int H, int hd, int64_t L, int64_t max_len, const float *outliers,
-                     const int32_t *outlier_idx, int n_out, int accumulate, void *workspace, size_t workspace_bytes,
-                     void *stream) {
-  if (!p || !mat || !mul || !lut_rows || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 || L > max_len ||
-      bits < 2 || bits > 4)
-    return KVQ_EINVAL;
-  const bool sparse = outlier_idx != nullptr;     // (without `outliers`: compact rows, packed entries in outlier_idx)
-  if ((outliers && !outlier_idx) || (sparse && n_out <= 0)) return KVQ_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  if (L == 0) {
-    if (!accumulate) {
-      if (hipMemsetAsync(mul, 0, (size_t)q_len * H * hd * sizeof(float), st) != hipSuccess) return KVQ_ELAUNCH;
-    }
-    return KVQ_OK;
-  }
-  if (!workspace || workspace_bytes < ws_bytes(bits, q_len, H, L)) return KVQ_EWORKSPACE;
-  const bool fast = mix_fast_shape(mat, lut_rows, H, hd, L, max_len, bits);
-  if (!fast) {
-    if (fs || (sparse && !outliers)) return KVQ_EINVAL;      // (the row-per-lane fallback reads the reference format only)
-    MixPlan pl = plan_mix_rows(bits, q_len, H, L, sparse);
-    MixVArgs a;
-    a.p = p;
-    a.mat = reinterpret_cast<const uint32_t *>(mat);
-    a.lut_rows = lut_rows;
-    a.outliers = outliers;
-    a.idx = outlier_idx;
-    a.partial = reinterpret_cast<float *>(workspace);
-    a.H = H;
-    a.q_len = q_len;
-    a.L = L;
-    a.max_len = max_len;
-    a.tr = pl.tr;
-    a.n_ranges = pl.n_ranges;
-    a.ubg = pl.ubg;
-    a.n_units = pl.n_units;
-    a.n_out = n_out;
-    switch (bits) {
-      case 4: return launch_mix_rows<4>(a, pl, mul, accumulate, st);
-      case 3: return launch_mix_rows<3>(a, pl, mul, accumulate, st);
-      default: return launch_mix_rows<2>(a, pl, mul, accumulate, st);
-    }
-  }
-  MixArgs a;
-  a.p = p;
-  a.mat = reinterpret_cast<const uint32_t *>(mat);
-  a.lut_rows = lut_rows;
-  a.outliers = outliers;
-  a.idx = outlier_idx;
-  a.partial = reinterpret_cast<float *>(workspace);
-  a.H = H;
-  a.q_len = q_len;
-  a.L = L;
-  a.max_len = max_len;
-  a.tr = 0;
-  a.groups = 1;
-  a.n_units = 0;
-  a.n_out = n_out;
-  a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
-  a.scores = nullptr;
-  a.mz = nullptr;
-  a.parts = nullptr;
-  a.n_parts = 0;
-  a.sink = nullptr;
-  a.sink_probs = nullptr;
-  a.n_sink = 0;
-  a.v_sink = nullptr;
-  a.sink_out = nullptr;
-  a.inv = 0.f;
-#if KVQ_TRACE
-  a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
-  if (!a.trace) return KVQ_EINVAL;
-#endif
+int launch_mix_bits(int bits, MixArgs a, float *mul, int accumulate, hipStream_t st, const FusedSoftmax *fs) {
   switch (bits) {
     case 4: return launch_mix<4>(a, mul, accumulate, st, fs);
     case 3: return launch_mix<3>(a, mul, accumulate, st, fs);
@@ -1392,42 +895,4 @@ static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int
   }
 }
 
-int kvq_mix_v(int bits, const float *p, const int32_t *mat, float *mul, const float *lut_rows, int q_len,
-              int H, int hd, int64_t L, int64_t max_len, const float *outliers, const int32_t *outlier_idx,
-              int n_out, int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
-  return mix_v_any(bits, p, nullptr, mat, mul, lut_rows, q_len, H, hd, L, max_len, outliers, outlier_idx, n_out, accumulate,
-                   workspace, workspace_bytes, stream);
-}
-
-int kvq_mix_v_softmax(int bits, const float *scores, const float *parts, int n_parts, float inv_sqrt_hd,
-                      const uint16_t *sink_scores, uint16_t *sink_probs, int n_sink, const uint16_t *v_sink,
-                      float *probs, const int32_t *mat, float *mul, const float *lut_rows, int H, int hd, int64_t L,
-                      int64_t max_len, const float *outliers, const int32_t *outlier_idx, int n_out,
-                      int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
-  if (!scores || !parts || n_parts <= 0 || n_sink < 0 || H <= 0 || L <= 0) return KVQ_EINVAL;
-  if (n_sink > 0 && (!sink_scores || !sink_probs)) return KVQ_EINVAL;
-  if (v_sink != nullptr && (n_sink <= 0 || accumulate)) return KVQ_EINVAL;
-  const bool fast = mix_fast_shape(mat, lut_rows, H, hd, L, max_len, bits) && H <= VCfg<4>::MZ_HEADS;
-  if (!fast) {
-    // shapes the streaming kernel does not take: the two passes separately
-    if (!probs) return KVQ_EINVAL;
-    int rc = kvq_softmax_finish(scores, sink_scores, parts, n_parts, probs, sink_probs, H, L, n_sink, inv_sqrt_hd, v_sink,
-                                mul, stream);
-    if (rc) return rc;
-    return mix_v_any(bits, probs, nullptr, mat, mul, lut_rows, 1, H, hd, L, max_len, outliers, outlier_idx, n_out,
-                     v_sink ? 1 : accumulate, workspace, workspace_bytes, stream);
-  }
-  FusedSoftmax f;
-  f.scores = scores;
-  f.parts = parts;
-  f.n_parts = n_parts;
-  f.inv = inv_sqrt_hd;
-  f.sink = reinterpret_cast<const __half *>(sink_scores);
-  f.sink_probs = reinterpret_cast<__half *>(sink_probs);
-  f.n_sink = n_sink;
-  f.v_sink = reinterpret_cast<const __half *>(v_sink);
-  return mix_v_any(bits, scores, &f, mat, mul, lut_rows, 1, H, hd, L, max_len, outliers, outlier_idx, n_out, accumulate,
-                   workspace, workspace_bytes, stream);
-}
-
-}  // extern "C"
+}  // namespace kvq

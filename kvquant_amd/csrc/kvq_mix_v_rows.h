@@ -31,14 +31,6 @@ constexpr int kChunk = 64;     // tokens per staged codebook chunk
 constexpr int kMixWaves = 4;
 constexpr int kSparseTokens = 2048;  // tokens per sparse workgroup
 
-template <int BITS>
-struct Unit {
-  static constexpr int kWords = BITS == 3 ? 3 : 1;                   // word-rows per unit
-  static constexpr int kCh = BITS == 4 ? 8 : (BITS == 3 ? 32 : 16);  // channels per unit
-  static constexpr int kPerHead = kHeadDim / kCh;
-  static constexpr int kBatch = BITS == 3 ? 8 : 16;  // tokens per register batch (16-byte loads)
-};
-
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 

@@ -8,41 +8,12 @@
 #ifndef KVQ_ABL
 #define KVQ_ABL 0      // ablation builds (tools/abl): timing experiments, results are wrong by construction
 #endif
-#ifndef KVQ_K_PF3
-#define KVQ_K_PF3 0            // with KVQ_K_SPARSE_AFTER: two heads of look-ahead in the mirror variant
-#endif
-#ifndef KVQ_K_SPARSE_AFTER
-#define KVQ_K_SPARSE_AFTER 0   // mirror variant: the outlier entries in batches after the head loop instead of one per head iteration
-#endif
-#ifndef KVQ_K_JIT
-#define KVQ_K_JIT 1            // mirror variant: packed-word registers are re-loaded for head h+2 as soon as head h has consumed them
-#endif
-#ifndef KVQ_K_PIPE
-#define KVQ_K_PIPE 0           // experiment (measured neutral): 4 bit, look-ups of batch b+1 issued before the FMAs of batch b
-#endif
-#ifndef KVQ_K_WEAVE
-#define KVQ_K_WEAVE 0          // 4 bit, mirror variant: the latency chains of a head iteration -- next table's DMA issue, the outlier
-#endif                         //  entry (angle shuffle, sincos, q look-ups, pair merge, score-tile update) -- are cut into
-                               //  pieces and issued between the look-up batches of the dense section instead of after it
-#ifndef KVQ_K_PRIO
-#define KVQ_K_PRIO 0           // experiment (measured neutral): wave priority (s_setprio): 1 = high while a wave is
-#endif                         //  in its latency-bound phases (top of the head, outlier step), low in the look-up loop; 2 = the
-                               //  two workgroups of a CU take turns (head parity, second half of the grid inverted); 3 = both
-#ifndef KVQ_K_NACC
-#define KVQ_K_NACC (KVQ_K_JIT ? 2 : 4)   // independent packed accumulators of the dense loop (4 bit)
-#endif
-#ifndef KVQ_K_LKB
-#define KVQ_K_LKB ((KVQ_K_PIPE || KVQ_K_WEAVE) ? 2 : 4)    // rotation pairs per look-up batch (4 bit): 2 * LKB ds_read_b64 in flight per wave
-#endif
 #ifndef KVQ_TRACE
 #define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the head loop (tools/dbg/trace_k.py)
 #endif
-#ifndef KVQ_PAD_LDS
-#define KVQ_PAD_LDS 0   // development: extra LDS per workgroup (occupancy experiments)
-#endif
-#ifndef KVQ_K_TMASK
-#define KVQ_K_TMASK (-1)   // development: AND-mask on the token of the packed-word loads (L2-resident source)
-#endif
+// (the experiment switches of rounds 2-3 -- look-up software pipeline, woven outlier step, wave priorities, outlier
+//  entries after the head loop, a third table buffer -- were measured neutral or slower and are gone; DESIGN.md 3 keeps
+//  the numbers)
 #include <cmath>
 #include <cstdlib>
 
@@ -121,10 +92,9 @@ struct KGeom {
   static constexpr int TAB_B = KTab<BITS>::BUF_B;
   static constexpr int SCS = kSparseHpg;
   static constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
-  static constexpr bool LATE_Q = TRANSPOSED && KVQ_K_SPARSE_AFTER && KVQ_K_PF3;
-  static constexpr int PF = (SPARSE && !LATE_Q) ? 2 : 3;
-  static constexpr int QL_B = (SPARSE && !LATE_Q) ? kSparseHpg * kHeadDim * 4 : 0;
-  static constexpr int SMEM_B = PF * TAB_B + SC_B + QL_B + KVQ_PAD_LDS;
+  static constexpr int PF = SPARSE ? 2 : 3;
+  static constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 0;
+  static constexpr int SMEM_B = PF * TAB_B + SC_B + QL_B;
   static constexpr int SC_OFF = PF * TAB_B;            // the [T][SCS] score tile
 };
 
@@ -156,10 +126,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   // look-ahead depth in heads: words and table of head hh+PF-1 are requested at the top of head hh.  The
   // kernel is bound by bytes in flight (Little's law at ~2 us loaded HBM latency), not by issue: the dense
   // variant has the registers and the LDS for two heads of look-ahead, the sparse one for one.
-  // (mirror variant with KVQ_K_PF3: the outlier entries are handled after the head loop, so q in LDS is only needed
-  //  then and takes over a table buffer: three buffers fit the same 80 KB)
-  constexpr bool LATE_Q = TRANSPOSED && KVQ_K_SPARSE_AFTER && KVQ_K_PF3;
-  constexpr int PF = (SPARSE && !LATE_Q) ? 2 : 3;
+  constexpr int PF = SPARSE ? 2 : 3;
   // JIT (mirror variant): two register sets, but a set is re-loaded for head h+2 while head h is still being decoded
   // -- each pair of word registers right after the batch that consumed it -- and the outlier entry of head h+2 right
   // after the one of head h has been used.  The loads of a head are then in flight for one to two head iterations
@@ -167,10 +134,8 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   // the barrier.  Memory operations return in order, so at the top of head h+1 `s_waitcnt vmcnt(JIT_OPS)` -- all but
   // the JIT_OPS operations issued during head h -- covers exactly what head h+1 needs: its table (issued at the top
   // of head h), its words and its outlier entry (issued during head h-1).
-  constexpr bool JIT = KVQ_K_JIT && TRANSPOSED && !KVQ_K_SPARSE_AFTER && PF == 2;
-  constexpr bool WEAVE = KVQ_K_WEAVE && JIT && BITS == 4;
-  // (WEAVE: the table pieces are issued behind the first two word re-loads of the head)
-  constexpr int JIT_OPS = 2 * BITS + (COMPACT ? 1 : 2) - (WEAVE ? 2 : 0) - ((KVQ_ABL & 1024) ? BITS : 0);
+  constexpr bool JIT = TRANSPOSED;
+  constexpr int JIT_OPS = 2 * BITS + (COMPACT ? 1 : 2) - ((KVQ_ABL & 1024) ? BITS : 0);
   // VMEM operations of one look-ahead step that EVERY wave issues (waves with an extra table piece wait
   // for one more than they need to)
   constexpr int STEP_OPS = 2 * BITS + TAB_DMA / NWAVES;
@@ -178,11 +143,11 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   // static LDS: every table offset below is a compile-time constant that folds into ds immediates
   // q of the group's heads for the sparse phase: 16 KB.  With 4-bit tables it aliases table buffer 1, which
   // is first written (by the DMA for the second head) after the sparse phase; smaller tables leave room.
-  constexpr int QL_B = (SPARSE && !LATE_Q) ? kSparseHpg * kHeadDim * 4 : 0;
-  static_assert(PF * TAB_B + SC_B + QL_B + KVQ_PAD_LDS == KGeom<BITS, SPARSE, NWAVES, TRANSPOSED>::SMEM_B, "KGeom");
+  constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 0;
+  static_assert(PF * TAB_B + SC_B + QL_B == KGeom<BITS, SPARSE, NWAVES, TRANSPOSED>::SMEM_B, "KGeom");
   unsigned char *lutq = smem;                                                    // [PF][TAB_B]
   float *sc = reinterpret_cast<float *>(smem + PF * TAB_B);                      // [T][SCS]
-  float *ql = reinterpret_cast<float *>(LATE_Q ? smem : smem + PF * TAB_B + SC_B);   // [hpg][128]
+  float *ql = reinterpret_cast<float *>(smem + PF * TAB_B + SC_B);   // [hpg][128]
   const uint32_t lds0 = lds_addr(smem);
 
   const int tid = threadIdx.x;
@@ -291,15 +256,14 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   auto theta_of = [&](int j) { return __shfl(th_reg, j); };
   if constexpr (SPARSE) {
     for (int i = tid; i < T * SCS; i += NT) sc[i] = 0.f;
-    if constexpr (!LATE_Q)
-      for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
+    for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
   }
 
   // packed words (role r: channel groups r and 2+r) of PF heads rotate through PF register sets
   uint32_t wlo_all[PF][BITS], whi_all[PF][BITS];
   float oldv[PF];   // dense + accumulate: the score's previous value travels with the head's words
   // lane offset inside a head's rows: role r starts BITS rows further down (host checks it fits 32 bits)
-  const uint32_t woff = (uint32_t)(((int64_t)role * BITS * a.max_len + (tc & KVQ_K_TMASK)) * 4);
+  const uint32_t woff = (uint32_t)(((int64_t)role * BITS * a.max_len + tc) * 4);
   const bool acc_dense = !SPARSE && a.accumulate;
   const uint32_t toff = (uint32_t)tc * 4u;
   auto load_old = [&](float &dst, int hh) {
@@ -409,10 +373,6 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   // every other asm load by tools/check_isa.py
   if constexpr (JIT) {
     // (both sets were requested above)
-  } else if constexpr (TRANSPOSED) {
-#if !KVQ_K_SPARSE_AFTER
-    if (nsteps > 0) sparse_fetch_t(0, spv_all[0], spc_all[0]);
-#endif
   } else if constexpr (SPARSE) {
     if (nchunks > 0) sparse_fetch(0, spv_all[0], spc_all[0]);
   }
@@ -500,29 +460,13 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
     // operations (no conditional definitions of the in-flight registers, constant wait counts): the last two heads
     // read their own rows once more (never used; just consumed, so the lines are still in the L2)
     const uint32_t *jit_row = mat_h0 + (int64_t)(hh + 2 < nh ? hh + 2 : hh) * head_words;
-    if constexpr (WEAVE) {
-      // (woven into the dense section below)
-    } else if constexpr (JIT) {
+    if constexpr (JIT) {
       if (hh + 1 < nh) issue_table(hh + 1, nxt);
     } else {
       if (hh + PF - 1 < nh) fetch_head(hh + PF - 1, std::integral_constant<int, nxt>{});
     }
 #if KVQ_TRACE
     stamp(3);
-#endif
-#if KVQ_K_PRIO
-    // The SIMD arbitrates between its four waves by priority, then age: with equal priorities the workgroup that was
-    // dispatched first wins every contended issue slot (measured: the first workgroup of a CU finishes its 32 heads in
-    // 63 us, the second in 87 us, and the kernel takes as long as the second).  A wave in the look-up loop is bound by
-    // throughput and does not care when exactly it issues; a wave on the latency chain around it does.
-    {
-      constexpr int lo = 0;
-      const int turn = (KVQ_K_PRIO & 2) ? ((hh + ((int)blockIdx.x >= (int)gridDim.x / 2 ? 1 : 0)) & 1) : 0;
-      __builtin_amdgcn_sched_barrier(0);
-      if (turn) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(lo);
-      __builtin_amdgcn_sched_barrier(0);
-    }
 #endif
     const unsigned char *tlo = lutq + buf * TAB_B;
     const unsigned char *thi = lutq + buf * TAB_B + KTab<BITS>::HALF_B;
@@ -533,164 +477,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
     // (JIT: a wave without tokens -- ragged last tile -- decodes its clamped token like the others, so that every wave
     //  issues the same operations per head; its results are dropped below)
     if ((wact || JIT) && !(KVQ_ABL & 64)) {
-    if constexpr (WEAVE) {
-      // Look-up batches of LKB rotation pairs; while a batch's look-ups travel, ONE piece of the head's latency chains
-      // is issued: its instructions are independent of the batch, their own round trips (LDS shuffles and reads, the
-      // DMA issue) overlap with the following batches.  sched_barrier(0) pins the order, the wait counts are hipcc's.
-      constexpr int LKB = KVQ_K_LKB, NA = KVQ_K_NACC, NB = 32 / LKB, BPW = 8 / LKB;
-      uint32_t elo = 0, olo = 0, ehi = 0, ohi = 0;
-      f32x2 vl[LKB], vh[LKB];
-      auto prep = [&](auto J) {
-        constexpr int j = decltype(J)::value;
-        const uint32_t woff_ = woff;
-        const uint32_t *row_lo = jit_row + j * a.max_len, *row_hi = jit_row + hi_words + j * a.max_len;
-        elo = ((wlo[j] << 3) & 0x78787878u) | rolepat;
-        olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
-        ehi = ((whi[j] << 3) & 0x78787878u) | rolepat;
-        ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
-        asm volatile("" ::"v"(elo), "v"(olo), "v"(ehi), "v"(ohi));
-        asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(wlo[j]) : "v"(woff_), "s"(row_lo) : "memory");
-        asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(whi[j]) : "v"(woff_), "s"(row_hi) : "memory");
-      };
-      auto issue = [&](auto B) {
-        constexpr int b = decltype(B)::value;
-        static_for<0, LKB>([&](auto NN) {
-          constexpr int i = LKB * b + decltype(NN)::value;
-          constexpr int n = i % 8;
-          const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
-          const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
-          vl[decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
-          vh[decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
-        });
-      };
-      auto accum = [&](auto B) {
-        constexpr int b = decltype(B)::value;
-        static_for<0, LKB>([&](auto NN) {
-          constexpr int nn = decltype(NN)::value;
-          constexpr int i = LKB * b + nn;
-          acc4[i & (NA - 1)] = __builtin_elementwise_fma(cs[i], vl[nn], acc4[i & (NA - 1)]);
-          acc4[(i + NA / 2) & (NA - 1)] = __builtin_elementwise_fma(cs[i], vh[nn], acc4[(i + NA / 2) & (NA - 1)]);
-        });
-      };
-      // ---- the outlier entry of this head (sparse_step_t, cut into stages) -------------------------------------------
-      const bool sp_on = hh < nsteps && !(KVQ_ABL & 128);          // (wave-uniform)
-      float sp_val = spv_all[buf & 1];
-      int sp_col = spc_all[buf & 1];
-      entry_of(sp_val, sp_col);
-      const int sp_hhE = (sp_col >> 7) - h0, sp_ch = sp_col & 127;
-      bool sp_use = false;
-      float sp_th = 0.f, sp_q1 = 0.f, sp_q2 = 0.f, sp_sn = 0.f, sp_c = 0.f, sp_x = 0.f, sp_xo = 0.f, sp_old = 0.f;
-      int sp_hk = 0, sp_ho = 0;
-      float *sp_cell = sc;
-      auto piece = [&](auto P) {
-        constexpr int p = decltype(P)::value;
-        if constexpr (p == 0) {
-          if (hh + 1 < nh) issue_table(hh + 1, nxt);
-        } else if constexpr (p == 1) {
-          // (no branches in here: the stages run for every lane, `sp_use` decides at the end -- control flow inside the
-          //  dense section splits it into blocks and the register allocation falls apart)
-          const bool s_ok = !(role == 1 && (a.n_out & 1) && hh == 0);
-          sp_use = sp_on && valid && s_ok && (sp_val != 0.f) && ((unsigned)sp_hhE < (unsigned)nh);
-          sp_th = theta_of(sp_ch & 63);
-          const int hq = sp_use ? sp_hhE : 0;
-          sp_q1 = ql[hq * kHeadDim + sp_ch];
-          sp_q2 = ql[hq * kHeadDim + (sp_ch ^ 64)];
-        } else if constexpr (p == 2) {
-          sincos_rev(sp_th * posf, sp_sn, sp_c);
-        } else if constexpr (p == 3) {
-          const float sg = (sp_ch < 64) ? sp_sn : -sp_sn;
-          sp_x = sp_use ? sp_val * fmaf(sp_c, sp_q1, sg * sp_q2) : 0.f;
-          sp_hk = sp_use ? sp_hhE : (-1 - role);
-          sp_ho = __shfl_xor(sp_hk, 32);
-          sp_xo = __shfl_xor(sp_x, 32);
-        } else if constexpr (p == 4) {
-          const bool same = sp_ho == sp_hk;
-          sp_x += (same && role == 0) ? sp_xo : 0.f;
-          sp_use = sp_use && !(same && role != 0);
-          const int hcell = sp_use ? sp_hhE : 0;
-          sp_cell = sc + tl * SCS + ((hcell + tl) & (SCS - 1));
-          sp_old = *sp_cell;
-        } else if constexpr (p == 5) {
-          // predicated store WITHOUT control flow (a branch in here splits the section and the register allocation falls
-          // apart): exec is narrowed to the lanes with a live entry inside one asm statement.  An unused lane must not
-          // write at all -- its partner lane may be updating that very cell.
-          {
-            const unsigned long long live = __builtin_amdgcn_ballot_w64(sp_use);
-            const uint32_t addr = lds_addr(sp_cell);
-            const float nv = sp_old + sp_x;
-            unsigned long long keep;
-            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
-                         : "=&s"(keep) : "v"(addr), "v"(nv), "s"(live) : "memory");
-          }
-          // ... and its registers take entry hh+2 (see the sparse part of the unwoven path)
-          sparse_fetch_t(hh + 2 < per_t ? hh + 2 : per_t - 1, spv_all[buf & 1], spc_all[buf & 1]);
-        }
-      };
-      static_for<0, NB>([&](auto B) {
-        constexpr int b = decltype(B)::value;
-        if constexpr (b % BPW == 0) prep(std::integral_constant<int, b / BPW>{});
-        issue(B);
-        __builtin_amdgcn_sched_barrier(0);
-        piece(B);
-        __builtin_amdgcn_sched_barrier(0);
-        accum(B);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    } else if constexpr (BITS == 4 && KVQ_K_PIPE) {
-      // software pipeline over batches of LKB rotation pairs (2 * LKB look-ups): the look-ups of batch b+1 are on
-      // their way while batch b is accumulated -- a wave that has the LDS to itself is no longer a chain of
-      // extract -> look-up -> wait -> FMA round trips.  sched_barrier(0) pins the order; the wait counts are hipcc's.
-      constexpr int LKB = KVQ_K_LKB, NA = KVQ_K_NACC, NB = 32 / LKB, BPW = 8 / LKB;
-      uint32_t elo = 0, olo = 0, ehi = 0, ohi = 0;
-      f32x2 vl[2][LKB], vh[2][LKB];
-      auto prep = [&](auto J) {
-        constexpr int j = decltype(J)::value;
-        // (named here, outside any dependent expression, so that clang captures them)
-        const uint32_t woff_ = woff;
-        const uint32_t *row_lo = jit_row + j * a.max_len, *row_hi = jit_row + hi_words + j * a.max_len;
-        elo = ((wlo[j] << 3) & 0x78787878u) | rolepat;
-        olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
-        ehi = ((whi[j] << 3) & 0x78787878u) | rolepat;
-        ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
-        if (JIT) {   // (a plain `if` on the constant: clang does not capture names that only a discarded branch uses)
-          asm volatile("" ::"v"(elo), "v"(olo), "v"(ehi), "v"(ohi));
-          asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(wlo[j]) : "v"(woff_), "s"(row_lo) : "memory");
-          asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(whi[j]) : "v"(woff_), "s"(row_hi) : "memory");
-        }
-      };
-      auto issue = [&](auto B) {
-        constexpr int b = decltype(B)::value;
-        static_for<0, LKB>([&](auto NN) {
-          constexpr int i = LKB * b + decltype(NN)::value;     // rotation pair
-          constexpr int n = i % 8;
-          const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
-          const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
-          vl[b & 1][decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
-          vh[b & 1][decltype(NN)::value] = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
-        });
-      };
-      auto accum = [&](auto B) {
-        constexpr int b = decltype(B)::value;
-        static_for<0, LKB>([&](auto NN) {
-          constexpr int nn = decltype(NN)::value;
-          constexpr int i = LKB * b + nn;
-          acc4[i & (NA - 1)] = __builtin_elementwise_fma(cs[i], vl[b & 1][nn], acc4[i & (NA - 1)]);
-          acc4[(i + NA / 2) & (NA - 1)] = __builtin_elementwise_fma(cs[i], vh[b & 1][nn], acc4[(i + NA / 2) & (NA - 1)]);
-        });
-      };
-      prep(std::integral_constant<int, 0>{});
-      issue(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<1, NB>([&](auto B) {
-        constexpr int b = decltype(B)::value;
-        if constexpr (b % BPW == 0) prep(std::integral_constant<int, b / BPW>{});
-        issue(B);
-        __builtin_amdgcn_sched_barrier(0);
-        accum(std::integral_constant<int, b - 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      accum(std::integral_constant<int, NB - 1>{});
-    } else if constexpr (BITS == 4) {
+    if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         // even / odd nibbles as bytes = role*128 + code*8
@@ -710,7 +497,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
           asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(whi[j]) : "v"(woff), "s"(jit_row + hi_words + j * a.max_len) : "memory");
 #endif
         }
-        constexpr int LKB = KVQ_K_LKB, NA = KVQ_K_NACC;
+        constexpr int LKB = 4, NA = 2;   // rotation pairs per look-up batch (2 * LKB ds_read_b64 in flight), packed accumulators
         static_for<0, 8 / LKB>([&](auto HH) {
           constexpr int hf = decltype(HH)::value;   // batches of LKB pairs = 2 * LKB look-ups each
           f32x2 vl[4], vh[4];
@@ -778,27 +565,13 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
       // are written out once after the last head
       if (role == 0 && wact) sc[tl * SCS + ((hh + tl) & (SCS - 1))] += res;
       __builtin_amdgcn_sched_barrier(0);   // keep the sparse chunk's temporaries out of the dense section
-#if KVQ_K_PRIO & 1
-      __builtin_amdgcn_s_setprio(3);       // latency chain: outlier step, loop back-edge, wait, barrier, table DMA
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      static_assert(!SPARSE || PF == 2 || LATE_Q, "the sparse look-ahead registers are a two-set ring");
+      static_assert(!SPARSE || PF == 2, "the sparse look-ahead registers are a two-set ring");
       // (when there is nothing left to fetch the set is "defined" by an empty asm instead: both paths then
       // define it in place and hipcc needs no merge copy -- which it would place inside the in-flight window)
-      if constexpr (WEAVE) {
-        // (the outlier entry was handled between the look-up batches)
-      } else if constexpr (JIT) {
+      if constexpr (JIT) {
         // entry hh of this lane's token (landed: the wait at the top of this head), then its registers take entry hh+2
         if (hh < nsteps && !(KVQ_ABL & 128)) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);
         sparse_fetch_t(hh + 2 < per_t ? hh + 2 : per_t - 1, spv_all[buf & 1], spc_all[buf & 1]);
-      } else if constexpr (TRANSPOSED) {
-#if !KVQ_K_SPARSE_AFTER
-        if (nsteps > 0) {
-          if (hh + 1 < nsteps) sparse_fetch_t(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);   // waited for by the next head's
-          else asm volatile("" : "=v"(spv_all[1 - (buf & 1)]), "=v"(spc_all[1 - (buf & 1)]));
-          if (hh < nsteps && !(KVQ_ABL & 128)) sparse_step_t(hh, spv_all[buf & 1], spc_all[buf & 1]);   // landed: this head's vm_wait<0>
-        }
-#endif
       } else if (nchunks > 0 && !(KVQ_ABL & 16)) {
         if (hh + 1 < nchunks) sparse_fetch(hh + 1, spv_all[1 - (buf & 1)], spc_all[1 - (buf & 1)]);
         else asm volatile("" : "=v"(spv_all[1 - (buf & 1)]), "=v"(spc_all[1 - (buf & 1)]));
@@ -862,17 +635,12 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
       asm volatile("" : "+v"(v), "+v"(cidx));   // (the values exist from here on)
       sparse_chunk(j, v, cidx);
     }
-    if constexpr (LATE_Q) {
-      __syncthreads();     // every wave is done with the table buffers: q takes over the first one
-      for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
-      __syncthreads();
-    }
     if constexpr (TRANSPOSED) {
       // entries beyond the number of heads of this workgroup (ragged-tile / small-group blocks): batches of
       // TB, so that the memory latency is paid per batch (the registers of the dense loop are free here;
       // fetch and wait are back to back, nothing can touch the destinations in between)
       constexpr int TB = 7;
-      for (int s0 = KVQ_K_SPARSE_AFTER ? 0 : nh; s0 < nsteps; s0 += TB) {
+      for (int s0 = nh; s0 < nsteps; s0 += TB) {
         float v[TB];
         int ci2[TB];
 #pragma unroll

@@ -11,7 +11,7 @@ from tests import scenario
 
 def _paths():
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    return sorted(glob.glob(os.path.join(here, "ref_*.npz")))
+    return sorted(glob.glob(os.path.join(here, "ref_nuq*.npz")))
 
 
 @pytest.mark.parametrize("path", _paths(), ids=lambda p: os.path.basename(p)[:-4])
