@@ -688,6 +688,12 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
                 if getattr(args, "compact", False):
                     traffic = None          # (the kept PMC bytes are those of the reference format)
                 traffic_src = tj.get("_source")
+                from kvquant_amd import build as kb
+                if traffic is not None and tj.get("_kernel_code_sha") != kb.kernel_source_hash():
+                    traffic = None      # (measured on other kernel code than the one running: not this launch's traffic)
+                    traffic_src = "stale: %s was measured on kernel code %s, this tree is %s (tools/pmc_run.sh + " \
+                                  "tools/pmc_traffic.py re-measure)" % (tj.get("_source"), tj.get("_kernel_code_sha"),
+                                                                        kb.kernel_source_hash())
             except Exception:
                 traffic = None
         if sharded:

@@ -47,6 +47,16 @@ extern "C" {
 #define KVQ_ELAUNCH (-2)   /* hipLaunch / runtime error, see kvq_last_hip_error() */
 #define KVQ_EWORKSPACE (-3) /* workspace missing or too small */
 
+/* major * 100 + minor.  History of the ABI:
+ *   200  round 2: one-call decode step (kvq_decode_step), prepared score tables
+ *   300  round 4: (a) every entry point that takes a token-contiguous outlier mirror (`outliers_t`, `outlier_idx_t`) or
+ *        outlier rows (`outliers`, `outlier_idx`) reads a NULL value array next to a non-NULL index array as the COMPACT
+ *        format -- index words are fp16 residual << 16 | channel -- where 200 fell back to the row layout / rejected it: a
+ *        caller that used to pass reference-format int32 indices without values must now pass both arrays;
+ *        (b) kvq_vopts NULL now means the reference's behaviour including its tie quirk (reference_tie_quirk = 1);
+ *        (c) new entries: kvq_mix_v_softmax_affine, kvq_mix_v_affine_*, kvq_fused_attend*, kvq_decode_step
+ *        fuse_softmax modes 2 and 3.  A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
+#define KVQ_ABI_MAJOR 3
 KVQ_API int kvq_version(void);
 KVQ_API const char *kvq_strerror(int code);
 /* last hipError_t seen by a failing call on this thread (0 = none) */

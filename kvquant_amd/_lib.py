@@ -100,6 +100,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_MAJOR = 3      # include/kvq.h: KVQ_ABI_MAJOR
 
 
 class KvqError(RuntimeError):
@@ -119,6 +120,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if l.kvq_version() // 100 != ABI_MAJOR:
+            raise KvqError("kvquant_amd: %s is ABI %d, this binding is written for major %d (include/kvq.h: kvq_version) "
+                           "-- rebuild it" % (LIB_PATH, l.kvq_version(), ABI_MAJOR))
         _lib = l
     return _lib
 

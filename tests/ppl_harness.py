@@ -155,12 +155,22 @@ def _deploy_arith_forward(self, hidden_states, position_embeddings=None, attenti
     w = w.masked_fill(~mask, float("-inf"))
     p = torch.softmax(w, dim=-1, dtype=torch.float32).half().float()
     out = torch.matmul(p, v).half()                                              # [H, T, hd]
+    npr = getattr(self, "kvq_nprompt", 0)
+    if npr > 0:
+        # the prompt's own rows: a parallel prefill attends to the UNQUANTISED fp16 K / V (ML:1861-1874, flash attention)
+        kh = self.k_proj.lin(hidden_states.half()).view(T, H, hd).transpose(0, 1)[:, :npr]
+        vh = self.v_proj.lin(hidden_states.half()).view(T, H, hd).transpose(0, 1)[:, :npr]
+        khr = kh * c16[:npr] + torch.cat((-kh[..., hd // 2:], kh[..., :hd // 2]), dim=-1) * s16[:npr]
+        sp = torch.matmul(qr[:, :npr].float(), khr.float().transpose(1, 2)) * (1.0 / math.sqrt(hd))
+        sp = sp.masked_fill(~mask[:npr, :npr], float("-inf"))
+        pp = torch.softmax(sp, dim=-1, dtype=torch.float32).half().float()
+        out[:, :npr] = torch.matmul(pp, vh.float()).half()
     out = out.transpose(0, 1).reshape(1, T, H * hd)
     return self.o_proj(out.to(hidden_states.dtype)), None
 
 
 @torch.no_grad()
-def sim_deploy_arith_ppl(model, ids, quantizers, bits, sparsity_threshold=0.99, first_few_fp16=-1, norm=False):
+def sim_deploy_arith_ppl(model, ids, quantizers, bits, sparsity_threshold=0.99, first_few_fp16=-1, norm=False, n_prompt=0):
     """simulated quantisation of K / V (the reference's functions) + the deployment path's attention arithmetic"""
     import types
     m = copy.deepcopy(model)
@@ -174,6 +184,7 @@ def sim_deploy_arith_ppl(model, ids, quantizers, bits, sparsity_threshold=0.99, 
                                     sparsity_threshold, first_few_fp16, norm)
         at.kvq_heads, at.kvq_hd, at.kvq_theta = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads, float(theta)
         at.kvq_ff = max(first_few_fp16, 0)
+        at.kvq_nprompt = n_prompt
         at.forward = types.MethodType(_deploy_arith_forward, at)
     return ppl_full_sequence(m, ids)
 
@@ -232,7 +243,7 @@ def run(layers=2, n_tokens=512, bits=4, first_few_fp16=0, vocab=32000, seed=0, n
     base = ppl_full_sequence(model, ids)
     ff = first_few_fp16 if first_few_fp16 else -1
     sim = sim_path_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm)
-    simd = sim_deploy_arith_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm)
+    simd = sim_deploy_arith_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm, n_prompt=n_prompt)
     ker = kernel_path_ppl(model, ids, quantizers, norm=norm, n_prompt=n_prompt)
     return {"layers": layers, "tokens": n_tokens, "bits": bits, "first_few_fp16": first_few_fp16, "vocab": vocab,
             "n_prompt": n_prompt, "norm": norm, "train_steps": train_steps, "ppl_fp16": base, "ppl_sim": sim, "ppl_sim_deploy_arith": simd,

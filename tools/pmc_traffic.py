@@ -35,5 +35,8 @@ for key, pat in (("score_k", "score_k_kernel"), ("mix_v", "mix_v_kernel")):
     if bits == "4":
         j[key][str(ctx)] = b
 j["_source"] = src
+sys.path.insert(0, ".")
+from kvquant_amd import build as kb  # noqa: E402
+j["_kernel_code_sha"] = kb.kernel_source_hash()      # bench.py drops the numbers when the kernels' code has changed since
 json.dump(j, open(out, "w"), indent=1)
 print(json.dumps(j))
