@@ -89,9 +89,10 @@ def synth_quantizer(bits, gen, dev):
 def synth_tokens(S, scale, shift, gen, dev):
     k = torch.randn(S, C, generator=gen, device=dev) * scale + shift
     v = torch.randn(S, C, generator=gen, device=dev)
-    for x in (k, v):
-        m = torch.rand(S, C, generator=gen, device=dev) < 0.01
-        x[m] *= 6.0
+    # (no boolean-mask indexing: it syncs with the host on every call, which is what made the 4-process one-GPU smoke run
+    #  of round 3 look hung -- DESIGN.md 6)
+    k = torch.where(torch.rand(S, C, generator=gen, device=dev) < 0.01, k * 6.0, k)
+    v = torch.where(torch.rand(S, C, generator=gen, device=dev) < 0.01, v * 6.0, v)
     return k.half(), v.half()
 
 
@@ -688,12 +689,12 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
                 if getattr(args, "compact", False):
                     traffic = None          # (the kept PMC bytes are those of the reference format)
                 traffic_src = tj.get("_source")
-                from kvquant_amd import build as kb
-                if traffic is not None and tj.get("_kernel_code_sha") != kb.kernel_source_hash():
+                from kvquant_amd import build as kbuild
+                if traffic is not None and tj.get("_kernel_code_sha") != kbuild.kernel_source_hash():
                     traffic = None      # (measured on other kernel code than the one running: not this launch's traffic)
                     traffic_src = "stale: %s was measured on kernel code %s, this tree is %s (tools/pmc_run.sh + " \
                                   "tools/pmc_traffic.py re-measure)" % (tj.get("_source"), tj.get("_kernel_code_sha"),
-                                                                        kb.kernel_source_hash())
+                                                                        kbuild.kernel_source_hash())
             except Exception:
                 traffic = None
         if sharded:
@@ -780,6 +781,9 @@ def main():
     # development (a box with ONE GPU): KVQ_BENCH_ONE_GPU=1 puts every rank on cuda:0 and moves the hand-overs over gloo
     # (RCCL refuses two ranks on one device) -- the multi-rank code paths of this file, not a measurement
     one_gpu = os.environ.get("KVQ_BENCH_ONE_GPU") == "1"
+    if os.environ.get("KVQ_BENCH_DUMP_AFTER"):      # development: where is every rank after N seconds (hang diagnosis)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["KVQ_BENCH_DUMP_AFTER"]), exit=True)
     if one_gpu:
         local = 0
     if torch.cuda.device_count() <= local:

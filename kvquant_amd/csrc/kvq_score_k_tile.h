@@ -66,14 +66,31 @@ __device__ __forceinline__ void load_words(uint32_t (&w)[BITS], const uint32_t *
   }
 }
 
-// byte `B` of x as a zero-extended dword, always ONE VALU instruction (hipcc otherwise splits the middle
-// bytes into shift + and)
-template <int B>
-__device__ __forceinline__ uint32_t byte_of(uint32_t x) {
+// 4-bit field extraction of the score kernel: nibble n of a packed word -> the variable part of its look-up address,
+// code * 8 + role * 128, in 1.25 VALU instructions per code (2 masks + 8 cuts per word; round 3: 4 pre-masks + 8 byte cuts).
+// The word is split once into its low nibbles, with the role bit planted at bit 4 of every byte, and its high nibbles,
+// with the role bit at bit 0 of every byte; a cut then lifts 8 bits that start 3 below the nibble -- three zeroed
+// bits, the nibble, the neighbouring role bit:
+//   low nibble of byte m >= 1: v_bfe_u32(lo, 8m - 3, 8);  m = 0: byte 0 shifted left by 3 (SDWA byte select);
+//   high nibble of byte m <= 2: v_bfe_u32(hi, 8m + 1, 8);  m = 3: v_alignbit_b32(role, hi, 25).
+struct NibSplit {
+  uint32_t lo, hi;
+};
+__device__ __forceinline__ NibSplit nib_split(uint32_t w, uint32_t role_lo, uint32_t role_hi) {
+  NibSplit r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r.lo) : "v"(w), "s"(0x0f0f0f0fu), "v"(role_lo));
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r.hi) : "v"(w), "s"(0xf0f0f0f0u), "v"(role_hi));
+  return r;
+}
+template <int NIB>
+__device__ __forceinline__ uint32_t nib_field(const NibSplit &x, uint32_t role, uint32_t three) {
+  constexpr int m = NIB / 2;
   uint32_t r;
-  if constexpr (B == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(r) : "v"(x));
-  else if constexpr (B == 3) asm("v_lshrrev_b32 %0, 24, %1" : "=v"(r) : "v"(x));
-  else asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(r) : "v"(x), "n"(8 * B));
+  if constexpr (NIB == 0)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(three), "v"(x.lo));
+  else if constexpr ((NIB & 1) == 0) asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(r) : "v"(x.lo), "n"(8 * m - 3));
+  else if constexpr (NIB == 7) asm("v_alignbit_b32 %0, %1, %2, 25" : "=v"(r) : "v"(role), "v"(x.hi));
+  else asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(r) : "v"(x.hi), "n"(8 * m + 1));
   return r;
 }
 
@@ -417,7 +434,8 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   };
 
   // per-lane constant part of every look-up address
-  const uint32_t rolepat = role ? 0x80808080u : 0u;     // 4 bit: role*128 in every byte
+  const uint32_t role_lo = role ? 0x10101010u : 0u, role_hi = role ? 0x01010100u : 0u, role_u = (uint32_t)role;   // 4 bit: nib_split
+  const uint32_t three = __builtin_amdgcn_readfirstlane(3);
   const uint32_t rolebytes = (uint32_t)role * N * 8;    // generic
 
   auto head = [&](auto BUF, int hh) {
@@ -480,12 +498,11 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
     if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        // even / odd nibbles as bytes = role*128 + code*8
-        const uint32_t elo = ((wlo[j] << 3) & 0x78787878u) | rolepat, olo = ((wlo[j] >> 1) & 0x78787878u) | rolepat;
-        const uint32_t ehi = ((whi[j] << 3) & 0x78787878u) | rolepat, ohi = ((whi[j] >> 1) & 0x78787878u) | rolepat;
+        // the words split into low / high nibbles with the role bit next to each (nib_field cuts code*8 + role*128 out)
+        const NibSplit xl = nib_split(wlo[j], role_lo, role_hi), xh = nib_split(whi[j], role_lo, role_hi);
         if constexpr (JIT) {
           // rows j of the lo / hi halves are consumed: their registers take the same rows of head hh+2
-          asm volatile("" ::"v"(elo), "v"(olo), "v"(ehi), "v"(ohi));
+          asm volatile("" ::"v"(xl.lo), "v"(xl.hi), "v"(xh.lo), "v"(xh.hi));
 #if KVQ_ABL & 256
           asm volatile("v_mov_b32 %0, %1" : "=v"(wlo[j]) : "v"(woff));
           asm volatile("v_mov_b32 %0, %1" : "=v"(whi[j]) : "v"(woff));
@@ -504,8 +521,8 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
           static_for<0, LKB>([&](auto NN) {
             constexpr int n = LKB * hf + decltype(NN)::value;
             constexpr int i = 8 * j + n;
-            const uint32_t fl = byte_of<n / 2>((n & 1) ? olo : elo);
-            const uint32_t fh = byte_of<n / 2>((n & 1) ? ohi : ehi);
+            const uint32_t fl = nib_field<n>(xl, role_u, three);
+            const uint32_t fh = nib_field<n>(xh, role_u, three);
 #if KVQ_ABL & 1
             vl[n & 3] = f32x2{__uint_as_float(fl), 1.f};
             vh[n & 3] = f32x2{__uint_as_float(fh), 1.f};

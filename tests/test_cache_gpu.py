@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def _paths():
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    return sorted(glob.glob(os.path.join(here, "ref_*.npz")))
+    return sorted(glob.glob(os.path.join(here, "ref_nuq*.npz")))
 
 
 @pytest.mark.parametrize("host_topk", [True, False], ids=["topk_args", "topk_gpu"])

@@ -19,48 +19,42 @@ def gpu():
     return torch.device("cuda:0")
 
 
-NORTH_STAR = 2e-3      # 0.01 on wikitext-2's 5.47, relative (BASELINE.json north_star)
+NORTH_STAR = 0.01 / 5.47   # BASELINE.json north_star: wikitext-2 perplexity within 0.01 of the reference's 5.47 = 1.83e-3 relative
+
+# BASELINE config 1 acceptance.  Real LLaMA-2-7B weights and wikitext-2 are not available offline; the stand-in is a
+# 2-layer Llama with the 7B head shape TRAINED (600 AdamW steps, tests/ppl_harness.py) on a synthetic Markov language
+# whose ideal perplexity is 5.48, evaluated on 2048 fresh tokens of it: a model that predicts (PPL ~ 9.3), so a relative
+# perplexity difference means here what it means in the north star.  Three comparators on the same model, tokens and
+# calibrated quantizers:
+#   sim   the reference's simulated path (quant/llama_simquant.py: fake-quantised k_proj / v_proj, fp32 attention);
+#   simd  the same fake-quantised K / V through the DEPLOYMENT path's arithmetic (fp16 score scaling and probabilities,
+#         ML:1972-1976; with a prompt: the prompt's rows over the unquantised K / V, ML:1861-1874) -- what the kernels
+#         have to reproduce;
+#   fp16  the unquantised model.
+# Bars are FIXED (no data-dependent xfail): measured over three draws in round 4 (profiles/r04_ppl_delta.jsonl) --
+#   nuq4 (+ prompt): |kernel - simd| <= 6.2e-4, |kernel - sim| <= 1.7e-3 (prompt: 4.3e-3, sim does not model the prefill);
+#   nuq3 + 5 sinks:  <= 2.3e-3 / 5.1e-3 (the reference's two paths pick V outliers differently -- quantile vs top-21 --
+#                    which moves a token's scale, and at 3 bit that shows);   nuq2 + Q-Norm: <= 3.7e-4 / 5.2e-3.
+PPL_CASES = [
+    # kw, bar vs simd, bar vs sim
+    (dict(bits=4), NORTH_STAR, 5e-3),
+    (dict(bits=4, n_prompt=1024), NORTH_STAR, 1e-2),
+    (dict(bits=3, first_few_fp16=5), 5e-3, 1e-2),
+    (dict(bits=2, norm=True), NORTH_STAR, 1e-2),
+]
 
 
-def _ppl(kw, n_tokens=1024):
+@pytest.mark.parametrize("kw,bar_simd,bar_sim", PPL_CASES, ids=["nuq4", "nuq4-prompt1024", "nuq3-sink5", "nuq2-qnorm"])
+def test_ppl_kernel_path_vs_reference_paths(gpu, kw, bar_simd, bar_sim):
     from tests import ppl_harness
-    r = ppl_harness.run(layers=2, n_tokens=n_tokens, vocab=4096, **kw)
+    r = ppl_harness.run(layers=2, n_tokens=2048, vocab=4096, train_steps=600, **kw)
     print(r)
-    assert math.isfinite(r["ppl_kernel"]) and math.isfinite(r["ppl_sim"])
-    # a gross error is a failure in every configuration
-    assert abs(r["rel_delta"]) < 2e-2 and abs(r["rel_delta_vs_deploy_arith"]) < 2e-2, r
-    return r
-
-
-def test_ppl_kernel_path_vs_simulated_path_nuq4(gpu):
-    """north star: wikitext-2 perplexity within 0.01 of the reference at nuq4 + 1 % (5.47 -> 2e-3 relative).  Here:
-    2-layer random-init Llama, 7B head shape, seeded random tokens (real weights and wikitext-2 are
-    not available offline).  What the kernels have to reproduce is the reference's quantisation evaluated in its
-    DEPLOYMENT path's dtype order (half scores divided in fp16, fp16 probabilities, ML:1972-1976): against that
-    simulation the bar is the north star's 2e-3 (measured 4e-4 .. 1.3e-3).  The reference's fp32 simulated path
-    (quant/llama_simquant.py) differs from its own deployment arithmetic by more than that on this proxy -- 4.7e-3 in
-    the run this bar was set from, a random-init model with PPL ~ 2.4x the vocabulary is a noise amplifier -- so the
-    distance to it is bounded at 1e-2 and reported, not claimed."""
-    r = _ppl(dict(bits=4))
-    assert abs(r["rel_delta_vs_deploy_arith"]) < NORTH_STAR, r
-    assert abs(r["rel_delta"]) < 1e-2, r
-    print("nuq4: kernel path vs deployment-arithmetic simulation %.1e (bar 2e-3), vs the fp32 simulated path %.1e; the two "
-          "simulations differ by %.1e" % (r["rel_delta_vs_deploy_arith"], r["rel_delta"],
-                                          (r["ppl_sim_deploy_arith"] - r["ppl_sim"]) / r["ppl_sim"]))
-
-
-@pytest.mark.parametrize("kw", [dict(bits=4, n_prompt=192), dict(bits=3, first_few_fp16=5), dict(bits=2, norm=True)])
-def test_ppl_other_configurations_known_deviations(gpu, kw):
-    """The other configurations of the harness are NOT claimed to meet the north-star bar on this random-init proxy
-    (a noise amplifier: PPL ~ vocabulary size): measured 3e-3 .. 4e-3 relative against the simulated path --
-      * a parallel prefill attends to the prompt's UNQUANTISED K / V, as the reference's does (ML:1861-1874), which is
-        not what the simulated path computes;
-      * nuq3 + sinks and nuq2 + Q-Norm are coarser quantisers, and the reference's own two paths differ on tie tokens.
-    The test only bounds them (2e-2, in _ppl) and reports which of them happen to meet 2e-3 in this run."""
-    r = _ppl(kw)
-    if not abs(r["rel_delta_vs_deploy_arith"]) < NORTH_STAR:
-        pytest.xfail("known deviation: %.1e relative vs the deployment-arithmetic simulation (north-star bar 2e-3; %.1e vs "
-                     "the fp32 simulated path)" % (r["rel_delta_vs_deploy_arith"], r["rel_delta"]))
+    assert math.isfinite(r["ppl_kernel"]) and math.isfinite(r["ppl_sim"]) and math.isfinite(r["ppl_fp16"])
+    assert r["ppl_fp16"] < 20, "the stand-in model did not train (ideal perplexity of the stream: 5.48)"
+    assert abs(r["rel_delta_vs_deploy_arith"]) < bar_simd, r
+    assert abs(r["rel_delta"]) < bar_sim, r
+    # quantisation is not a no-op: the kernel path is NOT the fp16 model (nuq4 measured >= 1.2e-3 away, coarser ones more)
+    assert abs(r["ppl_kernel"] - r["ppl_fp16"]) / r["ppl_fp16"] > 1e-4, r
 
 
 def test_driver_protocol(gpu, tmp_path):
