@@ -57,9 +57,11 @@ def parse():
                          "and matvec; NOT the reference's format, reported with its own algorithmic bytes)")
     ap.add_argument("--streams", type=int, default=0, help="decode streams in flight (default: one per rank)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent full copies instead of layer sharding")
-    ap.add_argument("--shard", choices=("layers", "tokens"), default="layers",
+    ap.add_argument("--shard", choices=("layers", "tokens", "heads"), default="layers",
                     help="N > 1: layers = the reference's placement, N streams pipelined through it (default); tokens = ONE "
-                         "stream whose context is split along the token axis (strong scaling, one all-gather per layer)")
+                         "stream whose context is split along the token axis (strong scaling, one all-gather per layer); "
+                         "heads = ONE stream, every rank holds H / N heads of every layer (strong scaling, one all-gather "
+                         "of the heads' outputs per layer)")
     ap.add_argument("--sweep", action="store_true", help="every BASELINE configuration, one JSON line each (1 GPU)")
     ap.add_argument("--retrieval", action="store_true", help="plant a retrievable token and check it (config 5 proxy)")
     ap.add_argument("--time-every", type=int, default=11,
@@ -569,6 +571,89 @@ def run_token_sharded(args, rank, world, dev, dist):
     }
 
 
+def run_head_sharded(args, rank, world, dev, dist):
+    """--shard heads: ONE decode stream, every rank holds H / N heads of every layer for all ctx tokens
+    (kvquant_amd.cache.HeadShard: the whole new token is appended into a full-width staging column on every rank --
+    the outlier selection is a property of the whole token --, the rank's heads are extracted, attended with the ordinary
+    kernels at H / N heads, and one all-gather per layer assembles [H, hd]: sharding.head_sharded_step).  Strong scaling.
+    Every rank draws the same synthetic tokens (a tensor-parallel model would all-gather the k / v slices instead)."""
+    from kvquant_amd import sharding
+    from kvquant_amd.cache import HeadShard
+    total = args.steps + args.warmup
+    max_len = (args.ctx + total + 8 + 63) // 64 * 64
+    h0, n = sharding.head_assignment(H, world)[rank]
+    if n == 0:
+        raise SystemExit("bench.py --shard heads: more ranks (%d) than heads (%d)" % (world, H))
+    gen = torch.Generator(device=dev).manual_seed(1234)          # the same quantizers / tokens / queries on every rank
+    t_setup = time.time()
+    layers = []
+    for li in range(args.layers):
+        quant, scale, shift = synth_quantizer(args.bits, gen, dev)
+        hs = HeadShard(args.bits, C, H, (h0, n), max_len, rope_theta=THETA, device=dev, stage_len=8192)
+        hs.load_lookup_table(quant, quant)
+        fill = torch.Generator(device=dev).manual_seed(77 + li)
+        done = 0
+        while done < args.ctx:
+            S = min(8192, args.ctx - done)
+            k, v = synth_tokens(S, scale, shift, fill, dev)
+            hs.pack(k.view(S, H, HD).permute(1, 2, 0).float(), v.view(S, H, HD).permute(1, 2, 0).float())
+            done += S
+        k, v = synth_tokens(total, scale, shift, gen, dev)
+        q = torch.randn(total, H, HD, generator=gen, device=dev).half()
+        layers.append((hs, q, k, v))
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+    gathered = torch.empty((1, H, HD), dtype=torch.float32, device=dev)
+
+    def step(st):
+        out = None
+        for hs, q, k, v in layers:
+            qq = q[st] if out is None else q[st] + out.view(H, HD).half() * 1e-3      # (a true dependency on the gather)
+            out = sharding.head_sharded_step(lambda: hs.attend(qq, k[st], v[st]), H, HD, out=gathered)
+        return out
+
+    for st in range(args.warmup):
+        step(st)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for st in range(args.warmup, total):
+        step(st)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    # a rank's algorithmic bytes per cached token and layer: its heads' share of the packed words, scores and
+    # probabilities -- and the WHOLE 42-wide outlier rows and codebook row (a shard's rows keep the token's width)
+    dense = C * args.bits // 8 * n // H
+    per_tok = (dense + 336 + 4 * n) + (dense + 336 + 4 * 2 ** args.bits + 4 * n)
+    achieved = args.layers * args.ctx * per_tok / (elapsed / args.steps) / 1e9
+    return {
+        "metric": "decode tokens/s, KV-cache hot path (%d layers), LLaMA-2-7B head shape, nuq%d 1%%-sparse @%dK ctx, ONE "
+                  "stream, heads split over %d GPU(s)" % (args.layers, args.bits, args.ctx // 1024, world),
+        "value": args.steps / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1000.0 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LLaMA-2-7B KV path: H=32 hd=128 layers=%d nuq%d + 1%% outliers, ctx=%d cached tokens, 1 stream"
+                               % (args.layers, args.bits, args.ctx),
+                   "ctx": args.ctx, "bits": args.bits, "layers": args.layers, "streams": 1,
+                   "parallelism": "head-sharded over %d GPU(s): %d of %d heads per GPU, whole-token append into a staging "
+                                  "column + extract, one all-gather of [heads, hd] f32 per layer" % (world, n, H)},
+        "roofline": {"bound": "hbm", "kernel": "score_k + mix_v per GPU (its heads' share of the bytes)", "achieved": achieved,
+                     "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "bytes_per_token": per_tok},
+        "cpu_baseline": None, "setup_s": t_setup,
+    }
+
+
 def cache_bytes_per_layer(bits, max_len, compact=False):
     """HBM bytes one layer's compressed K + V cache occupies for max_len token slots (kvquant_amd.cache.QuantK / QuantV):
     packed codes, outlier rows (+ the token-contiguous K mirror), the per-token V codebook rows"""
@@ -824,6 +909,8 @@ def main():
             print(json.dumps(r), flush=True)
     if args.shard == "tokens":
         res = run_token_sharded(args, rank, world, dev, dist)
+    elif args.shard == "heads":
+        res = run_head_sharded(args, rank, world, dev, dist)
     else:
         res = run_config(args, rank, world, dev, dist)
     if rank == 0:

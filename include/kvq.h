@@ -55,7 +55,7 @@ extern "C" {
  *        caller that used to pass reference-format int32 indices without values must now pass both arrays;
  *        (b) kvq_vopts NULL now means the reference's behaviour including its tie quirk (reference_tie_quirk = 1);
  *        (c) new entries: kvq_mix_v_softmax_affine, kvq_mix_v_affine_*, kvq_fused_attend*, kvq_decode_step
- *        fuse_softmax modes 2 and 3.  A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
+ *        fuse_softmax modes 2 and 3, kvq_extract_heads.  A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
 #define KVQ_ABI_MAJOR 3
 KVQ_API int kvq_version(void);
 KVQ_API const char *kvq_strerror(int code);
@@ -426,6 +426,22 @@ KVQ_API int kvq_softmax_stats(const float *parts, int n_parts, int H, float *sta
  * records of [H*hd floats: the shard's output][H x (max, normaliser): kvq_softmax_stats], e.g. the result of ONE
  * all-gather per layer; a shard without tokens carries (-inf, 0).  out: float [H][hd]. */
 KVQ_API int kvq_combine_shards(const float *packed, int n_shards, int H, int hd, float *out, void *stream);
+
+/* HEAD-sharded cache (SURVEY 8e "by head"; no counterpart in the reference, whose placement is by layer, ML:2428-2453):
+ * a rank that holds heads [h0, h0 + n_heads) of a layer appends the WHOLE token into a full-width staging cache with the
+ * ordinary append / pack entries above -- the outlier selection and V's codebook row are properties of the whole token
+ * (ML:742, 1093-1119), so every rank selects bit-identically -- and this call copies columns [src_col, src_col + n) of
+ * the staging caches into columns [dst_col, dst_col + n) of the shard's: the heads' packed words of K and V, the tokens' V
+ * codebook rows, and the outlier rows with the shard's entries kept (channel rebased by -h0*hd) and the other ranks'
+ * entries zeroed (value 0, channel clamped to the shard's first / last, so rows stay sorted; zero entries are skipped by
+ * the matvecs like the reference's capped-away slots, ML:745-747).  k_out_t_dst / k_idx_t_dst: the shard's
+ * token-contiguous K mirror [n_out][dst_max_len] or NULL.  n_out = 0: dense caches.  Reference outlier format only. */
+KVQ_API int kvq_extract_heads(int bits, int H, int hd, int h0, int n_heads, int n_out, const int32_t *k_src,
+                      const int32_t *v_src, int64_t src_max_len, int64_t src_col, const float *k_out_src,
+                      const int32_t *k_idx_src, const float *v_out_src, const int32_t *v_idx_src,
+                      const float *v_rows_src, int32_t *k_dst, int32_t *v_dst, int64_t dst_max_len, int64_t dst_col,
+                      float *k_out_dst, int32_t *k_idx_dst, float *k_out_t_dst, int32_t *k_idx_t_dst, float *v_out_dst,
+                      int32_t *v_idx_dst, float *v_rows_dst, int64_t n, void *stream);
 
 /* ---- prefill attention (the MFMA path of BASELINE config 4) ----------------------- */
 

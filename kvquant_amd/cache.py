@@ -55,7 +55,7 @@ class QuantK(nn.Module):
 
     def __init__(self, bits=2, hidden_size=4096, num_heads=32, max_position_embeddings=-1,
                  include_sparse=False, sparsity_threshold=0.99, rope_theta=10000, use_orig_sparse=False,
-                 first_few_fp16=0, device=None, compact=False):
+                 first_few_fp16=0, device=None, compact=False, outlier_width=None):
         super().__init__()
         if bits not in (2, 3, 4):
             raise ValueError("bits must be 2, 3 or 4")
@@ -79,8 +79,9 @@ class QuantK(nn.Module):
         dev = _default_device(device)
         self.kcache = torch.zeros((num_heads, (self.head_dim // 32) * bits, self.max_len), dtype=torch.int32,
                                   device=dev)
-        # the reference hard-codes 42 columns (ML:396); same value at 0.99 / 4096
-        self.num_outliers = 2 * _threshold_k(sparsity_threshold, hidden_size)
+        # the reference hard-codes 42 columns (ML:396); same value at 0.99 / 4096.  outlier_width: a HEAD SHARD of a wider
+        # layer (HeadShard below) keeps rows as wide as the whole token's selection
+        self.num_outliers = int(outlier_width) if outlier_width else 2 * _threshold_k(sparsity_threshold, hidden_size)
         # compact=True (opt-in, NOT the reference's format): the outliers of a token are kept ONLY as packed
         # entries fp16 residual << 16 | channel in the token-contiguous mirror -- 168 B per token instead of 336 (+336
         # for the reference-layout rows, which are not kept).  The residual is rounded to fp16 (relative 2^-11 of an
@@ -311,7 +312,8 @@ class QuantV(nn.Module):
     """Compressed value cache with per-token codebooks (ML:978-1385)."""
 
     def __init__(self, bits=2, hidden_size=4096, num_heads=32, max_position_embeddings=-1,
-                 include_sparse=False, sparsity_threshold=0.99, first_few_fp16=0, device=None, compact=False):
+                 include_sparse=False, sparsity_threshold=0.99, first_few_fp16=0, device=None, compact=False,
+                 outlier_width=None):
         super().__init__()
         if bits not in (2, 3, 4):
             raise ValueError("bits must be 2, 3 or 4")
@@ -332,7 +334,7 @@ class QuantV(nn.Module):
         self.vcache = torch.zeros((num_heads, (self.head_dim // 32) * bits, self.max_len), dtype=torch.int32,
                                   device=dev)
         self.vlen = 0
-        self.num_outliers = 2 * _threshold_k(sparsity_threshold, hidden_size)
+        self.num_outliers = int(outlier_width) if outlier_width else 2 * _threshold_k(sparsity_threshold, hidden_size)
         if include_sparse and self.compact:
             # compact=True (opt-in, see QuantK): rows of packed entries fp16 residual << 16 | channel in outlier_indices,
             # no value array: 168 B per token instead of 336
@@ -695,6 +697,115 @@ def shard_attention(kc, vc, q, k=None, v=None, pos_base=0, record=None):
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
               accumulate=False)
     return out, stats[:, 0], stats[:, 1]
+
+
+
+class HeadShard:
+    """Heads [h0, h0 + n_heads) of one layer's compressed KV cache, all tokens: the HEAD-sharded placement of SURVEY 8e
+    ("by head"; the reference itself places whole layers, ML:2428-2453).  Heads are independent until o_proj, so a rank
+    computes the complete attention output of its heads and ONE all-gather of [n_heads * hd] floats per layer assembles
+    the layer's (sharding.head_sharded_step).  What is NOT per head is the quantiser: a token's 21 + 21 outliers are
+    selected over all H * hd channels (ML:742, 1093-1096) and V's codebook row comes from the token's 22nd largest /
+    smallest value (ML:1086-1119).  Every rank therefore sees the WHOLE new token (in a tensor-parallel model: one
+    all-gather of the k / v slices) and appends it into a full-width staging column with the ordinary kernels --
+    bit-identical selection and codes on every rank -- and kvq_extract_heads moves its heads' words, the codebook row and
+    its share of the outlier entries (channels rebased, foreign entries zeroed) into the shard's own cache, which the
+    ordinary matvec kernels then read with H = n_heads.  Outlier rows stay 42 wide: a shard cannot know in advance how
+    many of a token's outliers fall into its heads.
+
+    `full_k` / `full_v`: the staging caches (full width, `stage_len` columns; they also own the quantiser tables),
+    `k` / `v`: the shard (QuantK / QuantV over n_heads heads).  Reference outlier format; no fp16 sink tokens."""
+
+    def __init__(self, bits, hidden_size, num_heads, heads, max_position_embeddings, sparsity_threshold=0.99,
+                 rope_theta=10000, device=None, stage_len=64):
+        h0, n = int(heads[0]), int(heads[1])
+        if not (0 <= h0 and n > 0 and h0 + n <= num_heads):
+            raise ValueError("HeadShard: heads (%d, %d) outside 0..%d" % (h0, n, num_heads))
+        self.bits, self.h0, self.n_heads, self.num_heads = bits, h0, n, num_heads
+        self.head_dim = hidden_size // num_heads
+        kw = dict(bits=bits, include_sparse=True, sparsity_threshold=sparsity_threshold, device=device)
+        self.full_k = QuantK(hidden_size=hidden_size, num_heads=num_heads, max_position_embeddings=stage_len,
+                             rope_theta=rope_theta, **kw)
+        self.full_v = QuantV(hidden_size=hidden_size, num_heads=num_heads, max_position_embeddings=stage_len, **kw)
+        width = self.full_k.num_outliers
+        self.k = QuantK(hidden_size=n * self.head_dim, num_heads=n, max_position_embeddings=max_position_embeddings,
+                        rope_theta=rope_theta, outlier_width=width, **kw)
+        self.v = QuantV(hidden_size=n * self.head_dim, num_heads=n, max_position_embeddings=max_position_embeddings,
+                        outlier_width=width, **kw)
+        self.stage_len = stage_len
+        self.device = self.k.device
+
+    @property
+    def klen(self):
+        return self.k.klen
+
+    def load_lookup_table(self, k_quantizer, v_quantizer, include_sparse=True, sparsity_threshold=0.99, norm=False):
+        """the layer's quantizers (deployment/llama.py:186-198) -> the staging caches; the shard reads its heads' slices"""
+        if not include_sparse:
+            raise ValueError("HeadShard is a Dense-and-Sparse cache")
+        self.full_k.load_lookup_table(k_quantizer, include_sparse, sparsity_threshold, norm)
+        self.full_v.load_lookup_table(v_quantizer, include_sparse, sparsity_threshold, norm)
+        fk, fv, k, v = self.full_k, self.full_v, self.k, self.v
+        lo, hi = self.h0, self.h0 + self.n_heads
+        c0, c1 = lo * self.head_dim, hi * self.head_dim
+        k.lut, k.norm, k.include_sparse, k.sparsity_threshold = fk.lut, fk.norm, True, sparsity_threshold
+        k.lookup_table = fk.lookup_table[lo:hi].contiguous()
+        k.lookup_table2 = fk.lookup_table2[lo:hi].contiguous() if fk.lookup_table2 is not None else None
+        k.lut_ends = fk.lut_ends[c0:c1].contiguous()
+        k.zeropoint = fk.zeropoint.flatten()[c0:c1].contiguous()
+        k.outlier_threshold_upper = fk.outlier_threshold_upper.flatten()[c0:c1].contiguous()
+        k.outlier_threshold_lower = fk.outlier_threshold_lower.flatten()[c0:c1].contiguous()
+        k.normscale, k.normoffset = fk.normscale, fk.normoffset
+        k._step_layer = None
+        for name in ("lut", "norm", "zeropoint", "normscale", "normoffset", "include_sparse", "sparsity_threshold"):
+            if hasattr(fv, name):
+                setattr(v, name, getattr(fv, name))
+        for name in ("_ns", "_no", "_tables_version"):
+            if hasattr(fv, name):
+                setattr(v, name, getattr(fv, name))
+        if fv.lookup_table2 is not None:
+            v.lookup_table2 = torch.zeros((v.max_len, 2 ** self.bits), dtype=torch.float32, device=self.device)
+        return self
+
+    def reset(self):
+        for c in (self.full_k, self.full_v, self.k, self.v):
+            c.reset()
+
+    def _extract(self, n):
+        if self.full_v.lookup_table2 is not None:
+            raise NotImplementedError("HeadShard: Q-Norm V rows are not carried into the shard yet")
+        ops.extract_heads(self.bits, self.h0, self.n_heads, self.full_k, self.full_v, self.k, self.v, 0, self.k.klen, n)
+        self.k.klen += n
+        self.v.vlen += n
+
+    def pack(self, k, v):
+        """prompt tokens: k, v [H, hd, S] (whole tokens, pre-RoPE keys) -> the shard's columns, through the staging
+        caches in pieces of stage_len tokens (QuantK / QuantV.parallel_pack: one launch each per piece)"""
+        S = k.shape[-1]
+        for s0 in range(0, S, self.stage_len):
+            n = min(self.stage_len, S - s0)
+            self.full_k.klen = 0
+            self.full_v.vlen = 0
+            self.full_k.parallel_pack(k[..., s0:s0 + n])
+            self.full_v.parallel_pack(v[..., s0:s0 + n])
+            self._extract(n)
+
+    def attend(self, q, k, v, record=None):
+        """one decode token: q [H, hd] post-RoPE query (or this shard's [n_heads, hd] slice), k / v [H * hd] the WHOLE new
+        token.  Appends it (staging column 0 -> extract) and returns f32 [1, n_heads, hd]: the complete, normalised attention
+        output of this shard's heads over all cached tokens (a view of `record` when given).  Library launches only."""
+        fk, fv = self.full_k, self.full_v
+        lut_off = fk.lookup_table2 if fk.norm else fk.lookup_table
+        ops.append_k_fused(self.bits, fk.kcache, fk.lookup_table, lut_off, k.flatten().float().contiguous(),
+                           fk.outlier_threshold_lower, fk.outlier_threshold_upper, fk.outliers, fk.outlier_indices,
+                           fk.num_outliers // 2, 0, fk.outliers_t, fk.outlier_indices_t)
+        ops.append_v_fused(self.bits, fv.vcache, fv.lookup_table, fv.lut, v.flatten().float().contiguous(), fv.outliers,
+                           fv.outlier_indices, fv.num_outliers // 2, 0, fv.vnorm_args())
+        self._extract(1)
+        if q.shape[0] == self.num_heads:
+            q = q[self.h0:self.h0 + self.n_heads]
+        out, _, _ = shard_attention(self.k, self.v, q.contiguous(), pos_base=0, record=record)
+        return out
 
 
 def combine_shards(outs, Ms, Zs):

@@ -548,6 +548,37 @@ def combine_shards(packed, n_shards, H, hd, out):
                    "kvq_combine_shards")
 
 
+def extract_heads(bits, h0, n_heads, src_k, src_v, dst_k, dst_v, src_col, dst_col, n):
+    """columns [src_col, src_col + n) of the full-width caches src_k / src_v (QuantK / QuantV) -> columns [dst_col, ...)
+    of the head shard dst_k / dst_v that holds heads [h0, h0 + n_heads): packed words, V codebook rows, the shard's share
+    of the outlier rows (+ K mirror) -- kvq_extract_heads"""
+    H, hd, src_max = _cache_dims(src_k.kcache, bits)
+    Hs, _, dst_max = _cache_dims(dst_k.kcache, bits)
+    if Hs != n_heads or _cache_dims(dst_v.vcache, bits)[0] != n_heads:
+        raise ValueError("extract_heads: the shard caches hold %d heads, not %d" % (Hs, n_heads))
+    sparse = src_k.include_sparse
+    if sparse and (src_k.outliers is None or dst_k.outliers is None):
+        raise NotImplementedError("extract_heads reads the reference outlier format (not compact caches)")
+    n_out = int(src_k.num_outliers) if sparse else 0
+    if sparse and (dst_k.num_outliers != n_out or dst_v.num_outliers != n_out):
+        raise ValueError("extract_heads: the shard's outlier rows must be as wide as the full token's (%d)" % n_out)
+    with _Dev(dst_k.kcache):
+        _lib.check(_L().kvq_extract_heads(
+            bits, H, hd, int(h0), int(n_heads), n_out, _i(src_k.kcache, "src kcache"), _i(src_v.vcache, "src vcache"),
+            src_max, int(src_col), _fo(src_k.outliers if sparse else None, "src k outliers"),
+            _io(src_k.outlier_indices if sparse else None, "src k outlier_indices"),
+            _fo(src_v.outliers if sparse else None, "src v outliers"),
+            _io(src_v.outlier_indices if sparse else None, "src v outlier_indices"),
+            _f(src_v.lookup_table, "src v lookup_table"), _i(dst_k.kcache, "dst kcache"), _i(dst_v.vcache, "dst vcache"),
+            dst_max, int(dst_col), _fo(dst_k.outliers if sparse else None, "dst k outliers"),
+            _io(dst_k.outlier_indices if sparse else None, "dst k outlier_indices"),
+            _fo(getattr(dst_k, "outliers_t", None) if sparse else None, "dst k outliers_t"),
+            _io(getattr(dst_k, "outlier_indices_t", None) if sparse else None, "dst k outlier_indices_t"),
+            _fo(dst_v.outliers if sparse else None, "dst v outliers"),
+            _io(dst_v.outlier_indices if sparse else None, "dst v outlier_indices"),
+            _f(dst_v.lookup_table, "dst v lookup_table"), int(n), _stream()), "kvq_extract_heads")
+
+
 # ---- one decode token through one layer, one library call -----------------------------------------------------------
 def make_layer(kc, vc, table, lut_off):
     """struct kvq_layer for a (QuantK, QuantV) pair: every pointer of the layer's compressed cache, built once and

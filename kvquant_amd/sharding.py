@@ -189,3 +189,48 @@ def token_sharded_step(shard_fn, record=None, group=None):
     dist.all_gather(bufs, packed, group=group)
     allp = torch.stack(bufs)                                                            # [R, H, hd + 2]
     return combine_shards(allp[:, None, :, :hd], allp[:, :, hd], allp[:, :, hd + 1])
+
+
+def head_assignment(num_heads, world):
+    """heads of every rank under the head-sharded placement: contiguous, as even as possible (the first num_heads % world
+    ranks hold one more) -> [(h0, n)] per rank"""
+    base, rem = divmod(num_heads, world)
+    out, h = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((h, n))
+        h += n
+    return out
+
+
+def head_sharded_step(attend_fn, num_heads, head_dim, group=None, out=None):
+    """One decode step of ONE stream whose heads are split over the ranks of `group` (`kvquant_amd.cache.HeadShard` on
+    each rank: heads [h0, h0 + n) of the layer, all tokens).  attend_fn() -> f32 [1, n, hd]: the complete, normalised
+    attention output of this rank's heads -- heads are independent until o_proj, so there is no softmax merge: ONE
+    all-gather of the outputs per layer (8 KB per rank at 4 of 32 heads; uneven splits are padded to the widest shard)
+    gives every rank the layer's [1, H, hd].  (In a tensor-parallel model a row-sharded o_proj would consume the local
+    slice and all-reduce its output instead; the gather is the form that matches the reference's full-width o_proj.)"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = attend_fn()
+    if world == 1:
+        return mine
+    split = head_assignment(num_heads, world)
+    widest = max(n for _, n in split)
+    rank = dist.get_rank(group)
+    send = mine.reshape(-1)
+    if split[rank][1] != widest:
+        send = torch.cat((send, send.new_zeros((widest - split[rank][1]) * head_dim)))
+    send = send.contiguous()
+    if send.is_cuda:
+        gathered = torch.empty(world * send.numel(), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(gathered, send, group=group)
+        parts = gathered.view(world, widest, head_dim)
+    else:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(bufs, send, group=group)
+        parts = torch.stack(bufs).view(world, widest, head_dim)
+    if out is None:
+        out = torch.empty((1, num_heads, head_dim), dtype=mine.dtype, device=mine.device)
+    for r, (h0, n) in enumerate(split):
+        out[0, h0:h0 + n] = parts[r, :n]
+    return out

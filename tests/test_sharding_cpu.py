@@ -166,6 +166,47 @@ def test_token_sharded_step_merges_exactly(world):
     assert all(err < 1e-5 for _, err in res), res
 
 
+def _head_shard_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kvquant_amd import sharding
+        H, hd = 7, 8                                             # (uneven over 2 and 3 ranks: the gather is padded)
+        full = torch.randn(1, H, hd, generator=torch.Generator().manual_seed(11))
+        h0, n = sharding.head_assignment(H, world)[rank]
+        out = sharding.head_sharded_step(lambda: full[:, h0:h0 + n].clone(), H, hd)
+        q.put((rank, bool(torch.equal(out, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_head_sharded_step_assembles_the_layer_output(world):
+    """sharding.head_sharded_step over gloo: every rank's heads land in their rows of the layer's [1, H, hd], uneven
+    splits included; head_assignment covers every head once, contiguously"""
+    import torch.multiprocessing as mp
+    from kvquant_amd import sharding
+    for Hn in (32, 7, 8):
+        for W in (1, 2, 3, 4, 8):
+            sp = sharding.head_assignment(Hn, W)
+            assert len(sp) == W and sp[0][0] == 0 and sum(n for _, n in sp) == Hn
+            assert all(sp[i][0] + sp[i][1] == sp[i + 1][0] for i in range(W - 1))
+            assert max(n for _, n in sp) - min(n for _, n in sp) <= 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_head_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
 # ---- the op order of StreamPipeline under the strictest p2p semantics (VERDICT r3 item 7) --------------------------------
 class _RecordingDist:
     """stands in for torch.distributed inside kvquant_amd.sharding: records the point-to-point calls of ONE rank in
