@@ -757,18 +757,27 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
     if rank == 0:
         L_mid = args.ctx + args.warmup + args.steps // 2
         k_us, v_us = timers.mean_us("score_k"), timers.mean_us("mix_v")
-        dom = "score_k" if (k_us or 0) >= (v_us or 0) else "mix_v"
-        dom_us = k_us if dom == "score_k" else v_us
-        dom_bytes, per_tok = algorithmic_bytes(args.bits, L_mid, dom, getattr(args, "compact", False))
-        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         kb, _ = algorithmic_bytes(args.bits, L_mid, "score_k", getattr(args, "compact", False))
         vb, _ = algorithmic_bytes(args.bits, L_mid, "mix_v", getattr(args, "compact", False))
+        from kvquant_amd import cache as kcache_mod
+        fused_attend = kcache_mod.FUSED_ATTEND if kcache_mod.FUSED_ATTEND is not None else L_mid >= kcache_mod.FUSED_ATTEND_FROM
+        if fused_attend:
+            # one kernel per layer (kvq_fused_attend: the library's event pairs are then the fused kernel and its merge);
+            # its algorithmic bytes: both matvecs' minus the score write / probability read that no longer exist
+            dom, dom_us = "fused_attend (q.K^T + softmax + p.V per tile)", k_us
+            dom_bytes = kb + vb - L_mid * 8 * H
+            per_tok = dom_bytes // L_mid
+        else:
+            dom = "score_k" if (k_us or 0) >= (v_us or 0) else "mix_v"
+            dom_us = k_us if dom == "score_k" else v_us
+            dom_bytes, per_tok = algorithmic_bytes(args.bits, L_mid, dom, getattr(args, "compact", False))
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(dom, {}).get("%d_%d" % (args.bits, args.ctx), tj.get(dom, {}).get(str(args.ctx)))
+                traffic = tj.get(dom, {}).get("%d_%d" % (args.bits, args.ctx), tj.get(dom, {}).get(str(args.ctx)))      # (fused: none kept)
                 if args.bits != 4 and ("%d_%d" % (args.bits, args.ctx)) not in tj.get(dom, {}):
                     traffic = None
                 if getattr(args, "compact", False):
@@ -810,11 +819,14 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
                          "timed_launches": len(timers.quads) or len(timers.pairs[dom]),
                          "timing": "HIP events on the launch stream around every %d-th layer's launch inside the timed region"
                                    % max(args.time_every, 1)},
-            "kernels": {"score_k_us": k_us, "mix_v_us": v_us,
-                        "score_k_GBps": kb / (k_us * 1e-6) / 1e9 if k_us else None,
-                        "mix_v_GBps": vb / (v_us * 1e-6) / 1e9 if v_us else None,
-                        "kv_matvec_GBps": (kb + vb) / ((k_us + v_us) * 1e-6) / 1e9 if k_us and v_us else None,
-                        "step_GBps": len(owned) * streams * (kb + vb) / (elapsed / args.steps) / 1e9},
+            "kernels": ({"fused_attend_us": k_us, "fused_merge_us": v_us,
+                         "kv_matvec_GBps": dom_bytes / ((k_us + v_us) * 1e-6) / 1e9 if k_us and v_us else None,
+                         "step_GBps": len(owned) * streams * dom_bytes / (elapsed / args.steps) / 1e9} if fused_attend else
+                        {"score_k_us": k_us, "mix_v_us": v_us,
+                         "score_k_GBps": kb / (k_us * 1e-6) / 1e9 if k_us else None,
+                         "mix_v_GBps": vb / (v_us * 1e-6) / 1e9 if v_us else None,
+                         "kv_matvec_GBps": (kb + vb) / ((k_us + v_us) * 1e-6) / 1e9 if k_us and v_us else None,
+                         "step_GBps": len(owned) * streams * (kb + vb) / (elapsed / args.steps) / 1e9}),
             "setup_s": t_setup,
         }
         if label:

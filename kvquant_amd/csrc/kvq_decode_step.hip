@@ -139,7 +139,7 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
     mark2_pending = true;
     // the affine form reads ONE constant table: the sorted codebook the rows are images of (fuse_softmax == 2, or rows
     // of another table -- Q-Norm at 2 bit: the per-row kernel)
-    const float *vtable = (fuse_softmax == 2 || ly->v_mix_rows) ? nullptr : ly->vlut_sorted;
+    const float *vtable = (fuse_softmax >= 2 || ly->v_mix_rows) ? nullptr : ly->vlut_sorted;   // (3 not taken: as 2)
     rc = kvq_mix_v_softmax_affine(bits, scores, parts, p.n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs,
                                   ly->vmat, out, vrows, vtable, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0,
                                   ws + p.mix_off, p.mix_b, stream);

@@ -59,6 +59,34 @@ def test_fused_matches_separate_kernels(bits, ctx):
     assert torch.equal(a.k.kcache, b.k.kcache) and torch.equal(a.v.vcache, b.v.vcache)
 
 
+def test_fused_is_the_default_from_512k_tokens_and_matches_the_separate_kernels():
+    """1M cached tokens (config 5's shape, one layer): decode_kv picks the fused kernel by itself (FUSED_ATTEND = None ->
+    L >= FUSED_ATTEND_FROM); the same cache through the separate kernels (forced off) gives the same output"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from kvquant_amd import cache, ops
+    dev = torch.device("cuda:0")
+    ctx = 1048576
+    assert cache.FUSED_ATTEND is None and ctx >= cache.FUSED_ATTEND_FROM
+    a, gen = _layer(4, ctx, dev, 4242)
+    b, _ = _layer(4, ctx, dev, 4242)
+    k, v = bench.synth_tokens(2, a.scale, a.shift, gen, dev)
+    modes = []
+    real = ops.decode_step
+    ops.decode_step = lambda layer, col, q_, k_, v_, out, mode, *rest: (modes.append(mode), real(layer, col, q_, k_, v_, out, mode, *rest))[1]
+    try:
+        for step in range(2):
+            q = torch.randn(H, HD, generator=gen, device=dev).half()
+            oa, _ = cache.decode_kv(a.k, a.v, q, k[step], v[step])            # default
+            ob, _ = _step(b, q, k[step], v[step], False)                      # separate kernels
+            err = util.rel_err(oa.float().reshape(1, -1), ob.float().reshape(1, -1))
+            assert err < TOL, (step, err)
+    finally:
+        ops.decode_step = real
+    assert modes == [3, 2, 3, 2], modes
+
+
 @pytest.mark.parametrize("bits,ctx", [(3, 700), (4, 40000)])
 def test_fused_with_sink_tokens(bits, ctx):
     if not torch.cuda.is_available():
