@@ -760,7 +760,8 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
         kb, _ = algorithmic_bytes(args.bits, L_mid, "score_k", getattr(args, "compact", False))
         vb, _ = algorithmic_bytes(args.bits, L_mid, "mix_v", getattr(args, "compact", False))
         from kvquant_amd import cache as kcache_mod
-        fused_attend = kcache_mod.FUSED_ATTEND if kcache_mod.FUSED_ATTEND is not None else L_mid >= kcache_mod.FUSED_ATTEND_FROM
+        fused_attend = kcache_mod.FUSED_ATTEND if kcache_mod.FUSED_ATTEND is not None else \
+            (args.bits == 4 and L_mid >= kcache_mod.FUSED_ATTEND_FROM)
         if fused_attend:
             # one kernel per layer (kvq_fused_attend: the library's event pairs are then the fused kernel and its merge);
             # its algorithmic bytes: both matvecs' minus the score write / probability read that no longer exist

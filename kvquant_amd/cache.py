@@ -559,7 +559,8 @@ MIX_PER_ROW = os.environ.get("KVQ_MIX_AFFINE", "0") != "1"
 # One kernel for q.K^T + softmax + p.V per 256-token tile and a merge (kvq_fused_decode.hip: kvq_fused_attend) instead of
 # the score / p.V kernel pair.  Measured (profiles/r04_fused_decode.txt): slower at 32K (one tile per workgroup leaves
 # half the chip idle), equal at 128K, 3 % slower at 256K, 3.7 % FASTER at 1M (several generations of workgroups: K phases
-# overlap V phases) -> the default from FUSED_ATTEND_FROM cached tokens on.  KVQ_FUSED_ATTEND=1 / 0 forces it on / off.
+# overlap V phases; same box at 1M: nuq4 11.08 -> 10.72 ms/step, but nuq3 + sinks 10.87 -> 11.02 and nuq2 9.28 -> 9.81)
+# -> the default at 4 bit from FUSED_ATTEND_FROM cached tokens on.  KVQ_FUSED_ATTEND=1 / 0 forces it on / off.
 FUSED_ATTEND = {"1": True, "0": False}.get(os.environ.get("KVQ_FUSED_ATTEND", ""), None)
 FUSED_ATTEND_FROM = int(os.environ.get("KVQ_FUSED_ATTEND_FROM", str(512 * 1024)))
 
@@ -607,7 +608,7 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         sink_probs = None if sinks is None else torch.empty_like(sink_scores)
         L = kpos + 1
         fuse = FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO
-        fused = FUSED_ATTEND if FUSED_ATTEND is not None else L >= FUSED_ATTEND_FROM
+        fused = FUSED_ATTEND if FUSED_ATTEND is not None else (bits == 4 and L >= FUSED_ATTEND_FROM)
         mode = (3 if fused else (2 if MIX_PER_ROW else 1)) if fuse else 0
         ops.decode_step(cached[1], kpos, q, k, v, out, mode, sinks, v_sink, sink_probs)
         kc.klen += 1
