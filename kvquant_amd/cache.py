@@ -748,6 +748,9 @@ class HeadShard:
         """the layer's quantizers (deployment/llama.py:186-198) -> the staging caches; the shard reads its heads' slices"""
         if not include_sparse:
             raise ValueError("HeadShard is a Dense-and-Sparse cache")
+        if norm:
+            raise NotImplementedError("HeadShard: Q-Norm quantizers are not carried into the shards (the V rows of the "
+                                      "normalised codebook would have to travel with the extract)")
         self.full_k.load_lookup_table(k_quantizer, include_sparse, sparsity_threshold, norm)
         self.full_v.load_lookup_table(v_quantizer, include_sparse, sparsity_threshold, norm)
         fk, fv, k, v = self.full_k, self.full_v, self.k, self.v
@@ -768,8 +771,6 @@ class HeadShard:
         for name in ("_ns", "_no", "_tables_version"):
             if hasattr(fv, name):
                 setattr(v, name, getattr(fv, name))
-        if fv.lookup_table2 is not None:
-            v.lookup_table2 = torch.zeros((v.max_len, 2 ** self.bits), dtype=torch.float32, device=self.device)
         return self
 
     def reset(self):
@@ -777,8 +778,6 @@ class HeadShard:
             c.reset()
 
     def _extract(self, n):
-        if self.full_v.lookup_table2 is not None:
-            raise NotImplementedError("HeadShard: Q-Norm V rows are not carried into the shard yet")
         ops.extract_heads(self.bits, self.h0, self.n_heads, self.full_k, self.full_v, self.k, self.v, 0, self.k.klen, n)
         self.k.klen += n
         self.v.vlen += n
