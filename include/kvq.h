@@ -55,12 +55,19 @@ extern "C" {
  *        caller that used to pass reference-format int32 indices without values must now pass both arrays;
  *        (b) kvq_vopts NULL now means the reference's behaviour including its tie quirk (reference_tie_quirk = 1);
  *        (c) new entries: kvq_mix_v_softmax_affine, kvq_mix_v_affine_*, kvq_fused_attend*, kvq_decode_step
- *        fuse_softmax modes 2 and 3, kvq_extract_heads.  A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
+ *        fuse_softmax modes 2 and 3, kvq_extract_heads, kvq_rope_q_f16.  A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
 #define KVQ_ABI_MAJOR 3
 KVQ_API int kvq_version(void);
 KVQ_API const char *kvq_strerror(int code);
 /* last hipError_t seen by a failing call on this thread (0 = none) */
 KVQ_API int kvq_last_hip_error(void);
+
+/* RoPE of the decode query in fp16, the glue of the patched attention (ML:1851-1853: query_states * cos +
+ * rotate_half(query_states) * sin on fp16 tensors) as ONE launch with the same roundings -- both products and the sum
+ * rounded to fp16 --, bit-identical to the three torch kernels.  q, out: fp16 [H][128]; cosv, sinv: fp16 [128], the
+ * position's row of the reference's rotary tables. */
+KVQ_API int kvq_rope_q_f16(const uint16_t *q, const uint16_t *cosv, const uint16_t *sinv, uint16_t *out, int H, int hd,
+                   void *stream);
 
 /* The 64 RoPE frequencies theta_j = powf(rope_theta, -2j/128) exactly as the score
  * kernels evaluate them -- on the device, like the reference (KCU:3081, 508, 584) --

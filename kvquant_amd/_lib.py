@@ -92,6 +92,7 @@ SIGNATURES = {
     "kvq_score_k_tables": (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_softmax_stats": (_i, [_vp, _i, _i, _vp, _vp]),
     "kvq_combine_shards": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "kvq_rope_q_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "kvq_extract_heads": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "kvq_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),

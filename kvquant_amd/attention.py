@@ -38,12 +38,25 @@ class RotaryDynamic(nn.Module):
         super().__init__()
         inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.int64).float().to(device) / dim))
         self.register_buffer("inv_freq", inv_freq, persistent=False)
+        self.dim, self.base = dim, float(base)
+
+    # The tables of the last positions asked for, per frequency table / device / dtype: every layer of a model asks for
+    # the SAME positions one after the other, and at decode the seven small launches below were a sizeable share of a
+    # layer's host time (profiles/r04_full_model.txt).  Same arithmetic, once per token instead of once per layer.
+    _last = {}
 
     def forward(self, x, start_pos, end_pos):
-        t = torch.arange(start_pos, end_pos, device=x.device, dtype=torch.int64).type_as(self.inv_freq)
-        freqs = torch.outer(t, self.inv_freq)
+        inv = self.inv_freq
+        key = (self.dim, self.base, inv.dtype, inv.device, x.dtype)
+        hit = RotaryDynamic._last.get(key)
+        if hit is not None and hit[0] == (start_pos, end_pos):
+            return hit[1], hit[2]
+        t = torch.arange(start_pos, end_pos, device=x.device, dtype=torch.int64).type_as(inv)
+        freqs = torch.outer(t, inv)
         emb = torch.cat((freqs, freqs), dim=-1)
-        return emb.cos().to(x.dtype), emb.sin().to(x.dtype)
+        cos, sin = emb.cos().to(x.dtype), emb.sin().to(x.dtype)
+        RotaryDynamic._last[key] = ((start_pos, end_pos), cos, sin)
+        return cos, sin
 
 
 class KVQuantAttention(nn.Module):
@@ -101,6 +114,18 @@ class KVQuantAttention(nn.Module):
         value_states = value_states.half()
         start = self.kcache.klen
         cos, sin = self.rotary_emb(value_states, start, start + q_len)
+        fused = self.kcache.include_sparse and self.vcache.include_sparse
+        if (q_len == 1 and fused and start >= sinks and query_states.dtype == torch.float16 and hd == 128
+                and (sinks == 0 or (self.fuse_sinks and self.kcache_fp16.dtype == torch.float16))):
+            # ---- decode over the compressed cache (ML:1948-2006), GPU-resident: the query's RoPE in one launch
+            # (kvq_rope_q_f16: torch's fp16 roundings), then one library call for the layer's KV path
+            q_rope = ops.rope_q_f16(query_states.reshape(H, hd), cos[0], sin[0])
+            if sinks > 0:
+                out, _ = decode_kv(self.kcache, self.vcache, q_rope, key_states.flatten(), value_states.flatten(),
+                                   k_sink=self.kcache_fp16[0], v_sink=self.vcache_fp16[0])
+            else:
+                out, _ = decode_kv(self.kcache, self.vcache, q_rope, key_states.flatten(), value_states.flatten())
+            return out.half().view(bsz, q_len, self.hidden_size)
         query_rope = (query_states * cos) + (rotate_half(query_states) * sin)
 
         if q_len > 1 and self.kcache.klen == 0:

@@ -102,6 +102,17 @@ def rope_freqs(theta, device=None):
     return out
 
 
+def rope_q_f16(q, cos, sin):
+    """q f16 [H, 128] (contiguous), cos / sin f16 [128] -> q * cos + rotate_half(q) * sin, f16 [H, 128], with torch's fp16
+    roundings (kvq_rope_q_f16): the decode query's RoPE of the patched attention in one launch"""
+    out = torch.empty_like(q)
+    with _Dev(q):
+        _lib.check(_L().kvq_rope_q_f16(_chk(q, torch.float16, "q"), _chk(cos, torch.float16, "cos"),
+                                       _chk(sin, torch.float16, "sin"), out.data_ptr(), q.shape[0], q.shape[1], _stream()),
+                   "kvq_rope_q_f16")
+    return out
+
+
 def append_k(bits, mat, lut, x, col):
     H, hd, max_len = _cache_dims(mat, bits)
     with _Dev(mat):

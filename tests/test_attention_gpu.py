@@ -196,3 +196,31 @@ def test_replay_reference_attention_module(name):
             t = S + i
             y = att2(hid[:, t:t + 1])
             assert util.rel_err(y.float().cpu().reshape(1, -1), ref_out[t:t + 1]) < 1e-2, i
+
+
+def test_rope_q_f16_is_bit_identical_to_the_torch_glue():
+    """kvq_rope_q_f16 (the decode query's RoPE in one launch) against the reference's expression on fp16 tensors
+    (ML:1851-1853: q * cos + rotate_half(q) * sin, three rounded torch kernels); and the rotary tables served from the
+    per-token cache are the tables computed afresh"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd import ops
+    from kvquant_amd.attention import RotaryDynamic, rotate_half
+    dev = torch.device("cuda:0")
+    rot = RotaryDynamic(128, base=10000.0, device=dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.zeros(1, dtype=torch.float16, device=dev)
+    for pos in (0, 1, 777, 131071, 1048575):
+        q = (torch.randn(32, 128, generator=g, device=dev) * 3).half()
+        RotaryDynamic._last.clear()
+        cos, sin = rot(x, pos, pos + 1)
+        cos2, sin2 = rot(x, pos, pos + 1)                       # (second layer of the same token: served from the cache)
+        assert cos2 is cos and sin2 is sin
+        want = (q[None, :, None, :] * cos) + (rotate_half(q[None, :, None, :]) * sin)
+        got = ops.rope_q_f16(q, cos[0], sin[0])
+        assert torch.equal(got, want[0, :, 0, :])
+    cos3, _ = rot(x, 5, 9)                                       # another range replaces the cached one
+    assert cos3.shape == (4, 128)
+    RotaryDynamic._last.clear()
+    cos4, _ = rot(x, 5, 9)
+    assert torch.equal(cos3, cos4)
