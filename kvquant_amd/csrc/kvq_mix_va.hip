@@ -123,7 +123,6 @@ struct Args {
   float inv;
   int n_dense;             // workgroups [0, n_dense): (range, unit group) of the dense stream; [n_dense, gridDim.x): outlier entries
   int64_t str;             // tokens per outlier workgroup
-  int dbg;                 // development (KVQ_VA_DBG): 1 no look-ups, 2 no DMA in the chunk loop, 4 no outlier phase, 8 no table build
 };
 
 __device__ __forceinline__ float mz_w(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
@@ -596,7 +595,7 @@ __global__ __launch_bounds__(V::NT, V::NT / 64 * V::WGPC / 4) void mix_va_kernel
   {
     f32x2 *tab = reinterpret_cast<f32x2 *>(smem + Cfg::PAIR_OFF);
     constexpr int NE = 1 << Cfg::PBITS;
-    for (int i = tid; i < NE * Cfg::R && !(a.dbg & 8); i += Cfg::NT) {
+    for (int i = tid; i < NE * Cfg::R; i += Cfg::NT) {
       const int b = i / Cfg::R;
       const int c0 = b & (Cfg::N - 1), c1 = b >> BITS;
       float x0 = 0.f, x1 = 0.f;
@@ -658,7 +657,6 @@ __global__ __launch_bounds__(V::NT, V::NT / 64 * V::WGPC / 4) void mix_va_kernel
   // the look-ups of one chunk.  TB >= 0: the tile's LDS offset as an instruction immediate (steady-state loop, one
   // unrolled copy per stage); TB < 0: `tbase` at run time
   auto dense = [&](auto TB, uint32_t tbase, uint32_t pbase, bool conv, int pb_next, int64_t c_next) {
-    if (a.dbg & 1) return;
     constexpr int TBV = decltype(TB)::value;
     constexpr int TBS = (TBV < 0 || TBV > 65000) ? 0 : TBV;           // (ds offsets are 16 bits)
     const uint32_t tbd = TBV < 0 ? tbase : (TBV > 65000 ? (uint32_t)TBV : 0u);
@@ -776,14 +774,13 @@ __global__ __launch_bounds__(V::NT, V::NT / 64 * V::WGPC / 4) void mix_va_kernel
         else if (extra1) vm_wait<Cfg::K_TILE + 1>();
         else vm_wait<Cfg::K_TILE>();
         __syncthreads();
-        const bool nodma = a.dbg & 2;
 #pragma unroll
         for (int k = 0; k < Cfg::K_TILE; k++)
-          if (!nodma) dma16_m0(tp + k * pstride, df.tile, (uint32_t)(Cfg::TILE_OFF + nst * Cfg::TILE_B + k * Cfg::NW * 1024) + wd16);
+          dma16_m0(tp + k * pstride, df.tile, (uint32_t)(Cfg::TILE_OFF + nst * Cfg::TILE_B + k * Cfg::NW * 1024) + wd16);
         tp += CT;
         const int pbn = (c + NS) % NPB;
-        if (has_p && !nodma) dma4_m0(sp, df.p, (uint32_t)Cfg::p_off(pbn) + wd4);
-        if (is_e && !nodma) dma4_m0(ep, df.e, (uint32_t)Cfg::e_off(pbn));
+        if (has_p) dma4_m0(sp, df.p, (uint32_t)Cfg::p_off(pbn) + wd4);
+        if (is_e) dma4_m0(ep, df.e, (uint32_t)Cfg::e_off(pbn));
         sp += CT;
         ep += CT * Cfg::N;
         dense(std::integral_constant<int, Cfg::TILE_OFF + st * Cfg::TILE_B>{}, 0u,
@@ -896,7 +893,7 @@ static int launch(Args a, float *mul, int accumulate, hipStream_t st) {
   a.n_units = pl.n_units;
   a.sink_out = mul;
   if (a.v_sink != nullptr) accumulate = 1;     // the reduce adds the slabs onto the sink tokens' output
-  const bool sparse = a.idx != nullptr && !(a.dbg & 4);
+  const bool sparse = a.idx != nullptr;
   const int n_sr = sparse ? pl.n_sranges : 0;
   a.n_dense = pl.n_ranges * pl.groups;
   a.str = pl.str;
@@ -914,26 +911,14 @@ static int launch(Args a, float *mul, int accumulate, hipStream_t st) {
   return launch_mix_reduce(a.partial, mul, pl.n_ranges + n_sr, 1, a.H * kHeadDim, accumulate, st);
 }
 
-// geometry variants (lanes, tokens per chunk, stages, table copies, workgroups per CU)
+// geometry (lanes, tokens per chunk, stages, table copies, workgroups per CU).  Measured and dropped
+// (profiles/r04_affine_pv.txt): 256 lanes (111.6 us at 128K), 32-token chunks with 16 copies on one workgroup per CU
+// (100.5 - 106.2), two stages with 32 copies (99.7 - 100.1); this one: 91.3 - 97.4
 typedef Var<512, 16, 3, 8, 2> V4A;
-typedef Var<256, 16, 3, 8, 2> V4B;
-typedef Var<512, 32, 3, 16, 1> V4C;
-typedef Var<512, 32, 2, 32, 1> V4D;
 typedef Var<512, 16, 2, 32, 2> V3A;
 
-static int variant4() {     // development: KVQ_VA_CFG=A|B|C|D
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("KVQ_VA_CFG");
-    v = (e && e[0] >= 'A' && e[0] <= 'D') ? e[0] - 'A' : 0;
-  }
-  return v;
-}
-
 static size_t plan_bytes(int bits, int H, int64_t L) {
-  if (bits == 3) return plan<ACfg<3, V3A>>(H, L).bytes;
-  size_t b = plan<ACfg<4, V4A>>(H, L).bytes, c = plan<ACfg<4, V4C>>(H, L).bytes;
-  return b > c ? b : c;       // (A / B and C / D share their range plans)
+  return bits == 3 ? plan<ACfg<3, V3A>>(H, L).bytes : plan<ACfg<4, V4A>>(H, L).bytes;
 }
 
 }  // namespace va
@@ -998,19 +983,9 @@ int kvq_mix_v_softmax_affine(int bits, const float *scores, const float *parts, 
   a.v_sink = reinterpret_cast<const __half *>(v_sink);
   a.sink_out = nullptr;
   a.inv = inv_sqrt_hd;
-  {
-    static int dbg = -1;
-    if (dbg < 0) dbg = getenv("KVQ_VA_DBG") ? atoi(getenv("KVQ_VA_DBG")) : 0;
-    a.dbg = dbg;
-  }
   hipStream_t st = (hipStream_t)stream;
   if (bits == 3) return va::launch<3, va::V3A>(a, mul, accumulate, st);
-  switch (va::variant4()) {
-    case 1: return va::launch<4, va::V4B>(a, mul, accumulate, st);
-    case 2: return va::launch<4, va::V4C>(a, mul, accumulate, st);
-    case 3: return va::launch<4, va::V4D>(a, mul, accumulate, st);
-    default: return va::launch<4, va::V4A>(a, mul, accumulate, st);
-  }
+  return va::launch<4, va::V4A>(a, mul, accumulate, st);
 }
 
 }  // extern "C"
