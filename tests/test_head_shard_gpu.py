@@ -141,3 +141,25 @@ def test_head_sharded_step_over_real_shards():
         for r in range(world):
             assert (ret[r][st] - ref).abs().max().item() <= 1e-3 * (ref.abs().max().item() + 1e-6), (st, r)
         assert torch.equal(ret[0][st], ret[1][st])
+
+
+def test_extract_heads_argument_checks():
+    """violated preconditions come back as KVQ_EINVAL before any launch; n = 0 is a no-op"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd import _lib, ops
+    from kvquant_amd.cache import HeadShard
+    from tests import decode_check
+    dev = torch.device("cuda:0")
+    quant, _, _ = decode_check.quantizer(4, seed=1)
+    hs = HeadShard(4, C, H, (8, 8), 128, device=dev).load_lookup_table(quant, quant)
+    ops.extract_heads(4, 8, 8, hs.full_k, hs.full_v, hs.k, hs.v, 0, 0, 0)                    # nothing to move
+    with pytest.raises(_lib.KvqError):
+        ops.extract_heads(4, 28, 8, hs.full_k, hs.full_v, hs.k, hs.v, 0, 0, 1)               # heads 28..35 of 32
+    with pytest.raises(_lib.KvqError):
+        ops.extract_heads(4, 8, 8, hs.full_k, hs.full_v, hs.k, hs.v, 60, 0, 8)               # source columns past the end
+    with pytest.raises(_lib.KvqError):
+        ops.extract_heads(4, 8, 8, hs.full_k, hs.full_v, hs.k, hs.v, 0, 125, 8)              # destination columns past the end
+    with pytest.raises(ValueError):
+        ops.extract_heads(4, 8, 4, hs.full_k, hs.full_v, hs.k, hs.v, 0, 0, 1)                # the shard holds 8 heads, not 4
+    assert hs.k.klen == 0 and not bool(hs.k.kcache.any())
