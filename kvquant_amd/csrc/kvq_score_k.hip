@@ -108,6 +108,15 @@ void score_k_kernel(ScoreKArgs a) {
       }
     }
   }
+#if KVQ_TRACE
+  {   // exit stamp of the wave (slot 3 of the kernel-level timeline, kvq_score_k_tile.h)
+    unsigned long long rr;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr)::"memory");
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)
+      a.trace[(int64_t)1024 * 8 * 32 * 8 + ((int64_t)blockIdx.x * NWAVES + wave) * 8 + 3] = rr;
+  }
+#endif
 }
 
 static int cu_count() {

@@ -409,7 +409,15 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   // One entry of this lane's token (transposed mirror).  The lane owns its token's row of the score tile;
   // the only other lane that can touch the same (token, head) cell in the same instruction is the other
   // role half's lane of the same token, so the pair is merged into the role-0 lane first.
-  auto sparse_step_t = [&](int s2, float val, int col) {
+  // (two halves: sparse_eval is the latency chain -- angle shuffle, sincos, two q look-ups, pair merge -- and touches
+  //  nothing another entry depends on; sparse_commit is the read-modify-write of the score tile, which has to stay in
+  //  program order.  The tail below evaluates a whole batch before it commits, so that the chains overlap.)
+  struct SpEntry {
+    float x;
+    int hh;
+    bool use;
+  };
+  auto sparse_eval = [&](int s2, float val, int col) {
     entry_of(val, col);
     const bool s_ok = !(role == 1 && (a.n_out & 1) && s2 == 0);
     const int hhE = (col >> 7) - h0;
@@ -430,8 +438,12 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
       if (role == 0) x += xo;
       else use = false;
     }
-    if (use) sc[tl * SCS + ((hhE + tl) & (SCS - 1))] += x;
+    return SpEntry{x, hhE, use};
   };
+  auto sparse_commit = [&](const SpEntry &e) {
+    if (e.use) sc[tl * SCS + ((e.hh + tl) & (SCS - 1))] += e.x;
+  };
+  auto sparse_step_t = [&](int s2, float val, int col) { sparse_commit(sparse_eval(s2, val, col)); };
 
   // per-lane constant part of every look-up address
   const uint32_t role_lo = role ? 0x10101010u : 0u, role_hi = role ? 0x01010100u : 0u, role_u = (uint32_t)role;   // 4 bit: nib_split
@@ -656,7 +668,10 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
       // entries beyond the number of heads of this workgroup (ragged-tile / small-group blocks): batches of
       // TB, so that the memory latency is paid per batch (the registers of the dense loop are free here;
       // fetch and wait are back to back, nothing can touch the destinations in between)
-      constexpr int TB = 7;
+      // (evaluated as a batch, committed in order -- sparse_eval / sparse_commit; same box, profiles/r04_tail_batch.txt:
+      //  4K 27.3 -> 25.2 us, 32K 42.0 -> 40.4; the 4-wave tiles of short caches have the registers for a token's whole
+      //  half of 21 entries in one batch, the 8-wave tiles run at the 128-VGPR limit: 7)
+      constexpr int TB = NWAVES == 4 ? 21 : 7;
       for (int s0 = nh; s0 < nsteps; s0 += TB) {
         float v[TB];
         int ci2[TB];
@@ -669,12 +684,18 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
         vm_wait<0>();
 #pragma unroll
         for (int k = 0; k < TB; k++) asm volatile("" : "+v"(v[k]), "+v"(ci2[k]));   // (the values exist from here on)
+        // (entries past the end carry value 0: evaluated like the others, never committed)
+        SpEntry ev[TB];
 #pragma unroll
-        for (int k = 0; k < TB; k++)
-          if (s0 + k < nsteps) sparse_step_t(s0 + k, v[k], ci2[k]);
+        for (int k = 0; k < TB; k++) ev[k] = sparse_eval(s0 + k, v[k], ci2[k]);
+#pragma unroll
+        for (int k = 0; k < TB; k++) sparse_commit(ev[k]);
       }
     }
   }
+#if KVQ_TRACE
+  tstamp(6);       // (the outlier tails are done)
+#endif
   KTile kt;
   kt.tile_i = tile_i; kt.h0 = h0; kt.nh = nh; kt.ntok = ntok; kt.tl = tl; kt.role = role; kt.b = b;
   kt.tile0 = tile0; kt.t = t; kt.valid = valid;
