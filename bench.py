@@ -920,6 +920,9 @@ def main():
             a.retrieval = ctx >= 1048576 and not compact
             r = run_config(a, rank, world, dev, dist, label=label, with_baselines=False)
             print(json.dumps(r), flush=True)
+    if args.shard != "layers" and (args.sinks or getattr(args, "compact", False) or args.retrieval):
+        raise SystemExit("bench.py --shard %s: fp16 sink tokens, the compact outlier format and the retrieval check belong to the "
+                         "layer placement (cache.shard_attention / HeadShard carry the reference format without sinks)" % args.shard)
     if args.shard == "tokens":
         res = run_token_sharded(args, rank, world, dev, dist)
     elif args.shard == "heads":
