@@ -45,12 +45,28 @@
 #define KVQ_V_WGS 512           // workgroups the plan aims at (2 per CU)
 #define KVQ_V_WAVES 4           // waves per SIMD the register allocation aims at
 #define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles (64K tokens) the p.V workgroups merge the partials themselves
-#define KVQ_V_RB 24             // outlier phase: entries per lane and round
+#ifndef KVQ_V_RB
+#define KVQ_V_RB 24             // outlier phase: entries per lane and token block (one round of loads)
+#endif
+#ifndef KVQ_V_WIN
+#define KVQ_V_WIN 64            // development (profiles/r05_pv_outlier_phase.txt): slots of a row that the first / last of several unit groups would read from its end in sparse_phase_one
+#endif
 // (the experiment switches of rounds 2-3 -- wave priorities, 16-token chunks at 4 bit, the C++ look-up loops next to the
 //  hand-scheduled ones, DMA in one burst, the development ablations -- were measured neutral or slower and are gone;
 //  DESIGN.md 3 keeps the numbers)
 
 namespace kvq {
+
+// bytes / 4 of `ns` whole outlier rows
+__device__ __forceinline__ unsigned nent_row(int ns, int n_out) { return (unsigned)ns * (unsigned)n_out; }
+// buffer descriptor over [p, p + bytes) from values that ARE wave-uniform, made provably so (readfirstlane of the
+// descriptor's inputs: otherwise hipcc wraps every buffer load in a waterfall loop -- cdna_hip_programming.md T8 / T20)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, unsigned bytes) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 
 // FUSED: the second softmax pass (kvq_softmax_finish) happens inside this kernel -- the workgroups merge the
 // (max, sum) partials of the score kernel themselves and convert raw scores to probabilities in LDS, one chunk
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   // adds like any other slab.
 #if KVQ_TRACE
   unsigned tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned tr_prev;
+  unsigned tr_prev, tr_passes = 0;
   unsigned long long tr_t0, tr_r0;
   {
     unsigned long long tt;
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   // and only this group's heads of the probabilities to stage.  The entries are read once per group (from the L2: see
   // the block numbering above).  The phase runs after the dense loop (32.32 fixed-point LDS adds: exact, order
   // independent); nothing of it is live across the loop.
-  auto sparse_phase = [&]() {
+  auto sparse_phase_rows = [&]() {
     // LDS (aliases the pipeline stages): [0, SP_P_B) the probabilities of a block of the range's tokens for the group's
     // heads, [SP_P_B, ...) the fixed-point accumulators of the group's channels.  Staging p (coalesced, independent of the
     // entries) removes the second dependent memory round trip (entry -> head -> p gather): the phase is pure latency.
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     const int c_lo = u0 * CH;                                  // the group's channels: [c_lo, c_lo + cn)
     const int cn = n_units_valid * CH;
     const int HWv = (n_units_valid + Cfg::UPH - 1) / Cfg::UPH; // its heads: [h0, h0 + HWv)
-    constexpr int RB = KVQ_V_RB;    // entries per lane per round, all loads of a round in flight together
+    constexpr int RB = 24;          // entries per lane per round, all loads of a round in flight together
     // token blocks: the entries of a block fit one round (24 x 512 / 42 = 292 tokens), its probabilities the stage
     int sb = a.n_out > 0 ? (RB * Cfg::NT) / a.n_out : 0;
     if (sb > 320) sb = 320;
@@ -325,6 +341,153 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       sstamp(9);
 #endif
     }
+  };
+  auto sparse_phase_one = [&]() {
+    // ONE unit group (2 / 3 bit at H = 32: every entry of the range belongs to this workgroup).  Round 5: straight-line
+    // code -- all of a block's entries and the raw scores of its tokens are requested together through buffer descriptors
+    // (one 32-bit lane offset per load, no address pairs), every entry is evaluated without control flow (a padding
+    // entry adds 0 into a per-lane dummy accumulator) and nothing of the entry -> (token, head) arithmetic is kept
+    // across the loads.  Same box, 128K nuq3 + 5 sinks: p.V + reduce 93.6 -> 89.3 us (profiles/r05_pv_outlier_phase.txt).
+    // With two unit groups half of the entries a workgroup reads are the other group's: there the branch per entry of
+    // sparse_phase_rows (which skips them) is faster (4 bit: 89 vs 92 us), and windows of the sorted rows (32 of 42
+    // slots from the group's end, the rest in a second pass when some token needs it) are slower still: one workgroup
+    // in four takes the second pass, and the launch waits for the slowest (112 us).
+    float *pl = reinterpret_cast<float *>(smem);
+    long long *sacc = reinterpret_cast<long long *>(smem + Cfg::SP_P_B);
+    static_assert((Cfg::SMEM_B - Cfg::SP_P_B) / 8 >= Cfg::UW * CH + 64, "accumulators of all the group's channels + dummies");
+    const int c_lo = u0 * CH;                                  // the group's channels: [c_lo, c_lo + cn)
+    const int cn = n_units_valid * CH;
+    const int HWv = (n_units_valid + Cfg::UPH - 1) / Cfg::UPH; // its heads: [h0, h0 + HWv)
+    constexpr int RB = KVQ_V_RB;    // entries per lane and block, all loads in flight together
+    constexpr int PE = 16;          // staged probabilities per lane and batch
+    const int G = a.groups;
+    const bool edge_group = G > 1 && (g == 0 || g == G - 1);
+    const int j0 = edge_group ? (a.n_out < KVQ_V_WIN ? a.n_out : KVQ_V_WIN) : a.n_out;   // slots of the first window
+#if KVQ_TRACE
+    auto sstamp = [&](int k) {
+      unsigned long long tt;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+      tr_acc[k] += (unsigned)tt - tr_prev;
+      tr_prev = (unsigned)tt;
+    };
+#endif
+    for (int pass = 0; pass < 2; pass++) {
+      // window of this pass: slots [w_lo, w_lo + w_n) of every row
+      const int w_n = pass == 0 ? j0 : a.n_out - j0;
+      if (w_n <= 0) break;
+#if KVQ_TRACE
+      tr_passes++;
+#endif
+      const int w_lo = (g == 0 || !edge_group) ? (pass == 0 ? 0 : j0) : (pass == 0 ? a.n_out - j0 : 0);
+      // the slot next to the rest of the row: when an entry there still belongs to this group, the rest may too
+      const int edge_s = (g == 0 || !edge_group) ? w_n - 1 : 0;
+      const uint32_t w_magic = (uint32_t)(((1ull << 32) + (uint64_t)w_n - 1) / (uint64_t)w_n);
+      // token blocks: the entries of a block fit one round, its probabilities the stage
+      int sb = (RB * Cfg::NT) / w_n;
+      if (sb > Cfg::NT) sb = Cfg::NT;
+      if (sb > Cfg::SP_P_B / (4 * HWv) - 1) sb = Cfg::SP_P_B / (4 * HWv) - 1;
+      if (sb < 1) return;
+      int more = 0;
+      for (int64_t b0 = t0; b0 < t1; b0 += sb) {
+        const int ns = (t1 - b0 < sb) ? (int)(t1 - b0) : sb;     // tokens of the block
+        const unsigned nent = (unsigned)ns * (unsigned)w_n;      // <= RB * NT
+        // buffer descriptors over the block's entries and the group's score rows: every load below is a wave-uniform
+        // descriptor + ONE 32-bit lane offset (no 64-bit address pairs: 48 loads in flight per lane)
+        const __amdgpu_buffer_rsrc_t r_idx = uniform_rsrc(a.idx + b0 * a.n_out, nent_row(ns, a.n_out) * 4u);
+        const __amdgpu_buffer_rsrc_t r_val = uniform_rsrc(
+            compact ? reinterpret_cast<const float *>(a.idx + b0 * a.n_out) : a.outliers + b0 * a.n_out, nent_row(ns, a.n_out) * 4u);
+        const __amdgpu_buffer_rsrc_t r_p = uniform_rsrc((FUSED ? a.scores : a.p) + (int64_t)h0 * a.L + b0, 0x7ffffffcu);   // FUSED: raw scores, converted on the way
+        int row[RB];
+        float val[RB];
+        // (an opaque copy of the thread id per block: otherwise hipcc hoists the entry -> token divisions out of the
+        //  block loop and spills them)
+        unsigned tid_b = tid;
+        asm volatile("" : "+v"(tid_b));
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+          const unsigned e = j * Cfg::NT + tid_b;
+          const unsigned ec = e < nent ? e : nent - 1;
+          const unsigned tl = __umulhi(ec, w_magic);             // token within the block, slot within the window
+          const unsigned off = (ec + tl * (unsigned)(a.n_out - w_n) + (unsigned)w_lo) * 4u;
+          // (Compact rows: `r_val` aliases the packed array, the second load hits the line the first one fetched.)
+          const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_idx, off, 0, 0);
+          const float fv = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_val, off, 0, 0));
+          row[j] = compact ? (int)(w & 0xffffu) : (int)w;
+          val[j] = compact ? __half2float(__ushort_as_half((unsigned short)(w >> 16))) : fv;
+        }
+        const int nsp = ns | 1;                     // odd row stride: consecutive heads fall into different LDS banks
+        {
+          // the block's probabilities of the group's heads: lanes along the tokens (coalesced), PE loads per lane in flight
+          const float rns = 1.0f / (float)ns;
+          const unsigned nel = (unsigned)HWv * (unsigned)ns;
+          for (unsigned k0 = 0; k0 < nel; k0 += PE * Cfg::NT) {
+            float v[PE];
+#pragma unroll
+            for (int k = 0; k < PE; k++) {
+              const unsigned e = k0 + k * Cfg::NT + tid_b;
+              const unsigned ec = e < nel ? e : nel - 1;
+              const unsigned hh = (unsigned)(((float)ec + 0.5f) * rns);      // ec / ns (exact: the quotient is never within 0.5 / ns of an integer)
+              const unsigned tl = ec - hh * (unsigned)ns;
+              v[k] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_p, (hh * (unsigned)a.L + tl) * 4u, 0, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < PE; k++) {
+              const unsigned e = k0 + k * Cfg::NT + tid_b;
+              const unsigned ec = e < nel ? e : nel - 1;
+              const unsigned hh = (unsigned)(((float)ec + 0.5f) * rns);
+              const unsigned tl = ec - hh * (unsigned)ns;
+              if (e < nel)
+                pl[hh * nsp + tl] = FUSED ? prob_of(v[k], a.inv, mz[h0 + hh].x, mz[h0 + hh].y) : v[k];
+            }
+          }
+        }
+#if KVQ_TRACE
+        sstamp(6);
+#endif
+        __syncthreads();                            // staged probabilities visible
+#if KVQ_TRACE
+        sstamp(7);
+#endif
+        // (a second opaque copy: the entry -> (token, slot) arithmetic is done again instead of being kept -- spilled --
+        //  across the loads)
+        unsigned tid_c = tid;
+        asm volatile("" : "+v"(tid_c));
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+          const unsigned e = j * Cfg::NT + tid_c;
+          const unsigned ec = e < nent ? e : nent - 1;
+          const unsigned tl = __umulhi(ec, w_magic);
+          const unsigned sl_e = ec - tl * (unsigned)w_n;           // slot within the window
+          const unsigned rel = (unsigned)(row[j] - c_lo);          // channel within the group
+          const bool mine = e < nent && rel < (unsigned)cn;
+          const unsigned hh = mine ? (rel >> 7) : 0u;
+          const float pt = pl[hh * nsp + tl];
+          more |= (mine && sl_e == (unsigned)edge_s) ? 1 : 0;
+          // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
+          const float x = mine ? val[j] * pt : 0.f;
+          const float fl = floorf(x);
+          const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
+          const int hi = (int)fl;
+          const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
+          // (another group's entry, or none: + 0 into this lane's dummy accumulator -- no branch)
+          const unsigned slot = mine ? rel : (unsigned)(Cfg::UW * CH) + (tid_c & 63u);
+          atomicAdd(reinterpret_cast<unsigned long long *>(&sacc[slot]), fx);
+        }
+#if KVQ_TRACE
+        sstamp(8);
+#endif
+        // the stage may be rewritten / the sums are complete; does any token have entries of this group beyond the window?
+        more = __syncthreads_or(more);
+#if KVQ_TRACE
+        sstamp(9);
+#endif
+      }
+      if (!edge_group || !more) break;
+    }
+  };
+  auto sparse_phase = [&]() {
+    if (a.groups == 1) sparse_phase_one();
+    else sparse_phase_rows();
   };
   // the lane that stores a unit half's channels at the end (slot 0), its slice of the partial slab and of the accumulators
   // (computed from an opaque copy of the thread id wherever it is needed, so that none of it stays live across the dense
@@ -661,6 +824,8 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
         asm volatile("" : "+v"(q[i / 4]));
         o[i] += q[i / 4].x; o[i + 1] += q[i / 4].y; o[i + 2] += q[i / 4].z; o[i + 3] += q[i / 4].w;
       }
+#pragma unroll
+      for (int i = 0; i < CHL; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
     }
   } else if (sparse) {
     // (the dense sums wait in the slab during the phase, like the outlier sums of the other order during the loop)
@@ -688,7 +853,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       }
     }
   }
-  if (writer && (sparse_first || !sparse)) {
+  else if (writer) {      // (every path stores its own sums: nothing of `o` is live across the outlier phase)
 #pragma unroll
     for (int i = 0; i < CHL; i += 4) *reinterpret_cast<float4 *>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
   }
@@ -705,6 +870,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr)::"memory");
       tr[12] = tt - tr_t0;               // shader clocks of the wave
       tr[13] = rr - tr_r0;               // 100 MHz ticks of the wave
+      tr[14] = tr_passes;                // passes of the outlier phase
     }
   }
 #endif

@@ -46,9 +46,10 @@ struct VCfg {
   static constexpr int STAGES_B = 2 * LUT_B + NPB * P_B + 2 * TILE_B;
   static constexpr int RED_B = NT * CHL * 4;           // slot reduction (aliases the stages)
   // sparse phase after the loop (aliases the stages): staged probabilities of the workgroup's token share
-  // (37 KB: 288 tokens x 32 heads, odd row stride) + 32 KB of 64-bit accumulators (4096 channels in one pass)
+  // (37 KB: 512 tokens x 16 heads / 256 x 32, odd row stride) + 32 KB of 64-bit accumulators (4096 channels in one pass)
+  // + 64 dummy accumulators (one per lane of a wave: where the entries of other groups go, branch-free)
   static constexpr int SP_P_B = 37888;
-  static constexpr int SP_B = SP_P_B + 32768;
+  static constexpr int SP_B = SP_P_B + 32768 + 512;
   static constexpr int SMEM_0 = (STAGES_B > RED_B ? STAGES_B : RED_B);
   static constexpr int SMEM_B = SMEM_0 > SP_B ? SMEM_0 : SP_B;
   static constexpr int MZ_HEADS = 128;                 // fused softmax: (max, normaliser) of every head, behind everything else

@@ -196,6 +196,49 @@ def test_mix_v(qc, orc, bits, L, q_len, sparse):
     assert err < TOL, err
 
 
+@pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("L", [700, 40000])
+@pytest.mark.parametrize("skew", ["low", "high", "33+9", "9+33", "one_channel", "mixed"])
+def test_mix_v_skewed_outlier_rows(qc, orc, bits, L, skew):
+    """The streaming p.V kernel lets the first / last unit group of a 4-bit launch read a 32-slot window of the
+    channel-sorted outlier rows from its end and takes the rest in a second pass when some token has more entries of
+    that group (kvq_mix_v.hip, sparse_phase): rows whose 42 entries sit entirely / mostly in one half of the channels,
+    rows that all name the same channels (same-address LDS adds), against the oracle."""
+    n = 2 ** bits
+    max_len = (L + 64 + 63) // 64 * 64          # aligned rows: the streaming kernel, not the row-per-lane fallback
+    mat = _random_cache(bits, L, max_len, 5 + L)
+    g = torch.Generator().manual_seed(L + 7)
+    rows = torch.zeros(max_len, n)
+    rows[:L] = util.centroids(bits).unsqueeze(0) * (torch.rand(L, 1, generator=g) + 0.5) + torch.randn(L, 1, generator=g) * 0.1
+    p = torch.softmax(torch.randn(1, H, L, generator=g) * 2, dim=-1).half().float().contiguous()
+    vals = torch.zeros(max_len, 42)
+    idx = torch.zeros(max_len, 42, dtype=torch.int32)
+    half = C // 2
+    for t in range(L):
+        kind = skew if skew != "mixed" else ["low", "high", "33+9", "9+33", "uniform"][t % 5]
+        if kind == "low":
+            ch = torch.randperm(half, generator=g)[:42]
+        elif kind == "high":
+            ch = half + torch.randperm(half, generator=g)[:42]
+        elif kind == "33+9":
+            ch = torch.cat((torch.randperm(half, generator=g)[:33], half + torch.randperm(half, generator=g)[:9]))
+        elif kind == "9+33":
+            ch = torch.cat((torch.randperm(half, generator=g)[:9], half + torch.randperm(half, generator=g)[:33]))
+        elif kind == "one_channel":
+            ch = torch.arange(42) * 97 + 5          # every token names the same 42 channels
+        else:
+            ch = torch.randperm(C, generator=g)[:42]
+        idx[t] = torch.sort(ch).values.int()
+    vals[:L] = torch.randn(L, 42, generator=g) * 3
+    name = "vecquant%dmatmul_nuq_perchannel_transposed_mha_batched_fused_opt2" % bits
+    ref = torch.zeros(1, H, HD)
+    out = torch.zeros(1, H, HD).cuda()
+    getattr(orc, name)(p, mat, ref, rows, L, vals, idx)
+    getattr(qc, name)(p.cuda(), mat.cuda(), out, rows.cuda(), L, vals.cuda(), idx.cuda())
+    err = util.rel_err(out.cpu().reshape(1, -1), ref.reshape(1, -1))
+    assert err < TOL, err
+
+
 def test_bad_arguments_raise(qc):
     m = torch.zeros(H, 16, 8, dtype=torch.int32).cuda()
     lut = torch.zeros(H, HD, 16).cuda()

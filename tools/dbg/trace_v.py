@@ -52,3 +52,4 @@ tt = trace.view(512, 8, 16).cpu().double()
 life = tt[..., 13].mean(dim=1) / 100.0
 print("wave lifetime (us): blocks 0..255 mean %.1f, blocks 256..511 mean %.1f; even blocks %.1f, odd blocks %.1f; min %.1f max %.1f"
       % (life[:256].mean(), life[256:].mean(), life[0::2].mean(), life[1::2].mean(), life.min(), life.max()))
+print("outlier-phase passes per workgroup: mean %.2f, workgroups with a second pass: %d of %d" % (tt[:, 0, 14].mean(), int((tt[:, 0, 14] > 1).sum()), tt.shape[0]))

@@ -68,6 +68,41 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
                    : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(cs));
     }
     if (MODE == 4) { p0 += q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7; }
+
+    // ---- K kernel form with fp16 tables: ds_read_b32 of a half2 entry + v_dot2_f32_f16 against the lane's half2 (cos, sin)
+    if (MODE == 6 || MODE == 8) {
+      asm volatile("v_and_b32 %0, 0xff, %8\n v_and_b32 %1, 0xff, %9\n v_bfe_u32 %2, %8, 8, 8\n v_bfe_u32 %3, %9, 8, 8\n"
+                   "v_bfe_u32 %4, %8, 16, 8\n v_bfe_u32 %5, %9, 16, 8\n v_lshrrev_b32 %6, 24, %8\n v_lshrrev_b32 %7, 24, %9\n"
+                   : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3), "=v"(u4), "=v"(u5), "=v"(u6), "=v"(u7) : "v"(we), "v"(wo));
+    }
+    if (MODE == 7) { u0 = we & 0xff; u1 = wo & 0xff; u2 = u0; u3 = u1; u4 = u0; u5 = u1; u6 = u0; u7 = u1; }
+    if (MODE == 7 || MODE == 8) {
+      asm volatile("ds_read_b32 %0, %8 offset:0\n ds_read_b32 %1, %9 offset:128\n ds_read_b32 %2, %10 offset:256\n ds_read_b32 %3, %11 offset:384\n"
+                   "ds_read_b32 %4, %12 offset:512\n ds_read_b32 %5, %13 offset:640\n ds_read_b32 %6, %14 offset:768\n ds_read_b32 %7, %15 offset:896\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                   : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(u4), "v"(u5), "v"(u6), "v"(u7) : "memory");
+    }
+    if (MODE == 6) { v0 = __uint_as_float(u0); v1 = __uint_as_float(u1); v2 = __uint_as_float(u2); v3 = __uint_as_float(u3); v4 = __uint_as_float(u4); v5 = __uint_as_float(u5); v6 = __uint_as_float(u6); v7 = __uint_as_float(u7); }
+    if (MODE == 6 || MODE == 8) {
+      asm volatile("v_dot2_f32_f16 %0, %4, %12, %0\n v_dot2_f32_f16 %1, %5, %12, %1\n v_dot2_f32_f16 %2, %6, %12, %2\n v_dot2_f32_f16 %3, %7, %12, %3\n"
+                   "v_dot2_f32_f16 %0, %8, %12, %0\n v_dot2_f32_f16 %1, %9, %12, %1\n v_dot2_f32_f16 %2, %10, %12, %2\n v_dot2_f32_f16 %3, %11, %12, %3\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                   : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(pt));
+    }
+    if (MODE == 7) { a0 += v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7; }
+    // ---- 3-bit K pair form: ONE look-up (ds_read_b32 of a half2 pair-sum entry, 6-bit index) + one v_dot2 per TWO codes:
+    // per 8 codes 4 field cuts, 4 look-ups, 4 dot2 (+ the word merges, 6 ops per 10 pairs -> 2.4 per 8 codes)
+    if (MODE == 9) {
+      asm volatile("v_bfe_u32 %0, %4, 0, 8\n v_bfe_u32 %1, %5, 8, 8\n v_bfe_u32 %2, %4, 16, 8\n v_lshrrev_b32 %3, 24, %5\n"
+                   "v_and_or_b32 %0, %0, %6, %7\n v_and_or_b32 %1, %1, %6, %7\n"
+                   : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3) : "v"(we), "v"(wo), "s"(0xfcu), "v"(w));
+      asm volatile("ds_read_b32 %0, %4 offset:0\n ds_read_b32 %1, %5 offset:256\n ds_read_b32 %2, %6 offset:512\n ds_read_b32 %3, %7 offset:768\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(u0 & 0xfc), "v"(u1 & 0xfc), "v"(u2 & 0xfc), "v"(u3 & 0xfc) : "memory");
+      asm volatile("v_dot2_f32_f16 %0, %4, %8, %0\n v_dot2_f32_f16 %1, %5, %8, %1\n v_dot2_f32_f16 %2, %6, %8, %2\n v_dot2_f32_f16 %3, %7, %8, %3\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(pt));
+    }
   }
   float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (p0 + p1 + p2 + p3).x + (p0 + p1 + p2 + p3).y;
   if (s == 12345.678f) out[0] = s;
@@ -92,6 +127,8 @@ int main() {
   float *d; hipMalloc(&d, 4096);
   RUN(0, "V form: bfe/and/lshr + v_fmac (no LDS)") RUN(1, "V form: 8 x ds_read_b32 only") RUN(2, "V form: extraction + ds_read_b32 + v_fmac")
   RUN(3, "K form: bfe/and/lshr + v_pk_fma (no LDS)") RUN(4, "K form: 8 x ds_read_b64 only") RUN(5, "K form: extraction + ds_read_b64 + v_pk_fma")
+  RUN(6, "K16 form: bfe/and/lshr + v_dot2_f32_f16 (no LDS)") RUN(7, "K16 form: 8 x ds_read_b32 (128 B apart) only") RUN(8, "K16 form: extraction + ds_read_b32 + v_dot2")
+  RUN(9, "K16 3-bit pair form: 4 cuts + 4 ds_read_b32 + 4 v_dot2 per 8 codes")
   printf("budget of the kernels at 128K: q.K^T 87 us and p.V 82 us over 8192 code-steps per SIMD = 10.6 / 10.0 ns per code-step\n");
   return 0;
 }
