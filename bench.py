@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--compact", action="store_true",
                     help="opt-in compact outlier formats (fp16 residual + 16-bit channel: 168 instead of 336 B per token "
                          "and matvec; NOT the reference's format, reported with its own algorithmic bytes)")
+    ap.add_argument("--score-f16", action="store_true",
+                    help="3 bit: q.K^T through the opt-in fp16 pair-sum tables (QuantK.score_f16_pair; scores within 4e-4 of "
+                         "the reference's, outputs within 4e-3 -- not the reference's rounding, hence not the default)")
     ap.add_argument("--streams", type=int, default=0, help="decode streams in flight (default: one per rank)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent full copies instead of layer sharding")
     ap.add_argument("--shard", choices=("layers", "tokens", "heads"), default="layers",
@@ -697,6 +700,7 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
     for s in range(streams):
         for li in owned:
             lay = Layer(args.bits, max_len, gen, dev, args.sinks, getattr(args, "compact", False))
+            lay.k.score_f16_pair = bool(getattr(args, "score_f16", False)) and args.bits == 3
             plant = None
             if args.retrieval and li == owned[0] and s == 0:
                 # query 3x the usual norm at the decode position; the planted key is the query rotated back to its
@@ -812,7 +816,9 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
                        "ctx": args.ctx, "bits": args.bits, "layers": args.layers, "sinks": args.sinks,
                        "streams": streams, "parallelism": par,
                        "outlier_format": "compact (fp16 residual + u16 channel, opt-in)" if getattr(args, "compact", False)
-                       else "reference (f32 + i32)"},
+                       else "reference (f32 + i32)",
+                       "score_tables": "fp16 pair-sum (opt-in)" if (getattr(args, "score_f16", False) and args.bits == 3)
+                       else "fp32 (query-premultiplied codebooks)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
@@ -910,13 +916,15 @@ def main():
                 ("32K", 32768, 4, 0, 32, 20, False),
                 ("128K nuq3 + 5 sinks (config 3)", 131072, 3, 5, 32, 10, False),
                 ("32K nuq3 + 5 sinks", 32768, 3, 5, 32, 20, False),
+                ("128K nuq3 + 5 sinks, fp16 pair-sum score tables (opt-in)", 131072, 3, 5, 32, 10, "f16"),
                 ("128K, compact outlier format (opt-in)", 131072, 4, 0, 32, 10, True),
                 ("128K nuq3 + 5 sinks, compact outlier format (opt-in)", 131072, 3, 5, 32, 10, True),
                 ("1M (config 5 shape on one GPU: 8 of 32 layers, retrieval proxy)", 1048576, 4, 0, 8, 5, False),
                 ("1M nuq3 + 5 sinks (8 of 32 layers)", 1048576, 3, 5, 8, 5, False)]
         for label, ctx, bits, sinks, layers, steps, compact in cfgs:
             a = argparse.Namespace(**base)
-            a.ctx, a.bits, a.sinks, a.layers, a.steps, a.compact = ctx, bits, sinks, layers, steps, compact
+            a.ctx, a.bits, a.sinks, a.layers, a.steps, a.compact = ctx, bits, sinks, layers, steps, compact is True
+            a.score_f16 = compact == "f16"
             a.retrieval = ctx >= 1048576 and not compact
             r = run_config(a, rank, world, dev, dist, label=label, with_baselines=False)
             print(json.dumps(r), flush=True)

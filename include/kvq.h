@@ -55,8 +55,14 @@ extern "C" {
  *        caller that used to pass reference-format int32 indices without values must now pass both arrays;
  *        (b) kvq_vopts NULL now means the reference's behaviour including its tie quirk (reference_tie_quirk = 1);
  *        (c) new entries: kvq_mix_v_softmax_affine, kvq_mix_v_affine_*, kvq_fused_attend*, kvq_decode_step
- *        fuse_softmax modes 2 and 3, kvq_extract_heads, kvq_rope_q_f16.  A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
-#define KVQ_ABI_MAJOR 3
+ *        fuse_softmax modes 2 and 3, kvq_extract_heads, kvq_rope_q_f16.
+ *   400  round 5: (a) struct kvq_layer grew (`flags` at the end): a caller compiled against 300 hands over a shorter struct;
+ *        (b) the constant-table p.V kernel left the library (kvq_mix_v_softmax_affine, kvq_mix_v_affine_*: measured slower
+ *        than the per-row kernel everywhere, tools/experiments/kvq_mix_va.hip keeps the source); kvq_decode_step
+ *        fuse_softmax 1 and 2 are the same route now;  (c) kvq_score_k_workspace_bytes is larger at 3 bit (the fp16
+ *        pair-sum tables live behind the fp32 ones);  (d) new entries: kvq_score_k_prepared_softmax_ex.
+ *        A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
+#define KVQ_ABI_MAJOR 4
 KVQ_API int kvq_version(void);
 KVQ_API const char *kvq_strerror(int code);
 /* last hipError_t seen by a failing call on this thread (0 = none) */
@@ -298,6 +304,22 @@ KVQ_API int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mu
                          const int32_t *outlier_idx_t, void *workspace,
                          size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts,
                          int n_parts, void *stream);
+/* As above with `flags`:
+ * KVQ_SCORE_F16_PAIR_TABLES (3 bit, token-contiguous mirror only; ignored elsewhere): the score kernel reads fp16
+ * PAIR-SUM tables -- the two channels of a rotation pair (k, k + 64) share their (cos, sin), so one table entry indexed by
+ * both codes holds the pre-added, query-premultiplied pair (64 entries x 4 B per pair, 16 KB per head; written by
+ * kvq_decode_prologue / kvq_score_k_tables next to the fp32 tables) and ONE LDS look-up + one v_dot2_f32_f16 replace two
+ * look-ups and two packed FMAs.  The entries and the (cos, sin) are rounded to fp16, the sums accumulate in fp32: scores
+ * agree with the fp32 tables to ~1e-4 of a row's largest score (contract: 1e-3; the reference rounds the scores
+ * themselves to fp16, modeling_llama.py:873).  128K nuq3: q.K^T 88 -> see DESIGN.md us. */
+#define KVQ_SCORE_F16_PAIR_TABLES 1
+KVQ_API int kvq_score_k_prepared_softmax_ex(int bits, const int32_t *mat, float *mul,
+                         const float *lut, int H, int hd, int64_t L, int64_t max_len,
+                         float rope_theta, int pos_offset, const float *outliers,
+                         const int32_t *outlier_idx, int n_out, const float *outliers_t,
+                         const int32_t *outlier_idx_t, void *workspace,
+                         size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts,
+                         int n_parts, int flags, void *stream);
 /* v_sink (optional, with sink_out): fp16 [H][n_sink][128] values of the sink tokens; the workgroup that writes
  * a head's sink probabilities also writes the sink tokens' share of the attention output,
  * sink_out[h][c] = float(half(sum_i sink_probs[h][i] * v_sink[h][i][c])) (torch.matmul in fp16, ML:1987-1995), so
@@ -322,24 +344,6 @@ KVQ_API int kvq_mix_v_softmax(int bits, const float *scores, const float *parts,
                       float inv_sqrt_hd, const uint16_t *sink_scores, uint16_t *sink_probs,
                       int n_sink, const uint16_t *v_sink, float *probs, const int32_t *mat, float *mul,
                       const float *lut_rows, int H, int hd, int64_t L, int64_t max_len,
-                      const float *outliers, const int32_t *outlier_idx, int n_out,
-                      int accumulate, void *workspace, size_t workspace_bytes, void *stream);
-
-/* kvq_mix_v_softmax on the affine structure of the per-token codebooks (kvq_mix_va.hip): every row of lut_rows is
- * table * sf_t + off_t (modeling_llama.py:1113; kvq_append_v_fused writes them so), hence
- *   sum_t p_t * lut_rows[t][code] = sum_t (p_t * sf_t) * table[code] + sum_t p_t * off_t :
- * one constant table in LDS, indexed by two codes at a time, instead of a 64-byte row per token.  sf_t / off_t are
- * recovered from the stored rows (first and last entry); the cache format is the reference's.  table: device float
- * [2^bits], the sorted codebook the rows were built from (QuantV.lut; the Q-Norm'ed one when lut_rows is
- * lookup_table2).  Agrees with kvq_mix_v_softmax to the rounding of the rows (~1e-7 relative per term; the north-star
- * tolerance of p.V is 1e-3).  3 and 4 bit, max_len % 4 == 0; everything else (and table == NULL) runs
- * kvq_mix_v_softmax.  workspace: kvq_mix_v_affine_workspace_bytes(bits, H, hd, L). */
-KVQ_API int kvq_mix_v_affine_supported(int bits, int H, int hd, int64_t L, int64_t max_len);
-KVQ_API size_t kvq_mix_v_affine_workspace_bytes(int bits, int H, int hd, int64_t L);
-KVQ_API int kvq_mix_v_softmax_affine(int bits, const float *scores, const float *parts, int n_parts,
-                      float inv_sqrt_hd, const uint16_t *sink_scores, uint16_t *sink_probs,
-                      int n_sink, const uint16_t *v_sink, float *probs, const int32_t *mat, float *mul,
-                      const float *lut_rows, const float *table, int H, int hd, int64_t L, int64_t max_len,
                       const float *outliers, const int32_t *outlier_idx, int n_out,
                       int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -391,7 +395,10 @@ typedef struct kvq_layer {
   int32_t *vidx;
   const kvq_vopts *vnorm;     /* optional */
   const float *v_mix_rows;    /* optional: table p.V dequantises with (lookup_table2 at 2 bit with Q-Norm), NULL = vlut_rows */
+  int flags;                  /* KVQ_LAYER_*: options of the decode step */
 } kvq_layer;
+/* kvq_layer.flags: 3-bit caches score through the fp16 pair-sum tables (KVQ_SCORE_F16_PAIR_TABLES above) */
+#define KVQ_LAYER_SCORE_F16_PAIR 1
 
 /* One decode token through one layer: K / V fused appends at column kcol (= vcol) + query tables, q.K^T with RoPE +
  * outliers + first softmax pass, softmax, p.V + outliers, slab reduce -- the launches of kvq_decode_prologue,
@@ -401,7 +408,7 @@ typedef struct kvq_layer {
  * all fp32 or all fp16.  sinks / v_sink / sink_probs: the fp16 attention-sink tokens (as kvq_decode_prologue /
  * kvq_softmax_finish), or NULL.  out f32 [H][hd]: the complete attention output.  Scores, probabilities, partials and
  * slabs live in `workspace` (kvq_decode_step_workspace_bytes(bits, H, hd, L) with L = kcol + 1; 256-byte aligned).
- * fuse_softmax: 0 = softmax as its own launch, 1 = inside the p.V kernel, 2 = as 1 with the per-row p.V kernel forced,
+ * fuse_softmax: 0 = softmax as its own launch, 1 (or 2) = inside the p.V kernel,
  * 3 = kvq_fused_attend (one kernel for q.K^T, softmax and p.V; shapes it does not take run as 1). */
 KVQ_API size_t kvq_decode_step_workspace_bytes(int bits, int H, int hd, int64_t L);
 KVQ_API int kvq_decode_step(const kvq_layer *layer, int64_t kcol, int64_t vcol, const void *q, const void *k,

@@ -40,7 +40,7 @@ class Layer(ctypes.Structure):
                 ("klut_ends", ctypes.c_void_p), ("klut_score", ctypes.c_void_p),
                 ("vmat", ctypes.c_void_p), ("vlut_rows", ctypes.c_void_p), ("vlut_sorted", ctypes.c_void_p),
                 ("voutliers", ctypes.c_void_p), ("vidx", ctypes.c_void_p), ("vnorm", ctypes.POINTER(VNorm)),
-                ("v_mix_rows", ctypes.c_void_p)]
+                ("v_mix_rows", ctypes.c_void_p), ("flags", ctypes.c_int)]
 
 
 _ly = ctypes.POINTER(Layer)
@@ -74,13 +74,11 @@ SIGNATURES = {
     "kvq_score_k_head_groups": (_i, [_i, _i64, _i, _i, _i]),
     "kvq_score_k_prepared_softmax": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                           _sz, _f, _vp, _i, _vp]),
+    "kvq_score_k_prepared_softmax_ex": (_i, [_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp,
+                                             _sz, _f, _vp, _i, _i, _vp]),
     "kvq_softmax_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp]),
     "kvq_mix_v_softmax": (_i, [_i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp, _vp, _i,
                                _i, _vp, _sz, _vp]),
-    "kvq_mix_v_affine_supported": (_i, [_i, _i, _i, _i64, _i64]),
-    "kvq_mix_v_affine_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
-    "kvq_mix_v_softmax_affine": (_i, [_i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64,
-                                      _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_fused_attend_supported": (_i, [_i, _i, _i, _i64, _i64, _i]),
     "kvq_fused_attend_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
     "kvq_fused_attend": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i,
@@ -103,7 +101,9 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_MAJOR = 3      # include/kvq.h: KVQ_ABI_MAJOR
+ABI_MAJOR = 4      # include/kvq.h: KVQ_ABI_MAJOR
+LAYER_SCORE_F16_PAIR = 1   # kvq_layer.flags
+SCORE_F16_PAIR_TABLES = 1  # kvq_score_k_prepared_softmax_ex flags
 
 
 class KvqError(RuntimeError):

@@ -105,6 +105,15 @@ class QuantK(nn.Module):
         self.norm = False
         self.lookup_table2 = None
         self.lut_ends = None
+        # OPT-IN (3 bit, GPU-resident decode path: decode_kv): q.K^T through fp16 PAIR-SUM tables -- the two channels of a
+        # rotation pair share (cos, sin), one table entry indexed by both codes holds their pre-added query-premultiplied
+        # values, so one LDS look-up + one v_dot2_f32_f16 replace two look-ups and two packed FMAs (include/kvq.h:
+        # KVQ_SCORE_F16_PAIR_TABLES): 128K nuq3 q.K^T 88.5 -> 70.6 us.  Entries and (cos, sin) are rounded to fp16, sums
+        # accumulate in fp32: <= 4e-4 of a row's largest score against the reference's kernel (contract 1e-3) -- but that is
+        # ~0.4 ulp of the fp16 value the reference rounds every score to (ML:873), so four scores in ten land on the
+        # neighbouring fp16 value and the attention OUTPUT moves by up to 2e-3 (tests/test_atsize_gpu.py).  Default False:
+        # the fp32 tables, whose scores round like the reference's.  Env KVQ_SCORE_F16=1 turns it on for every 3-bit cache.
+        self.score_f16_pair = bits == 3 and os.environ.get("KVQ_SCORE_F16", "0") == "1"
         self._reset_csr(dev)
 
     @property
@@ -552,10 +561,6 @@ FUSE_SOFTMAX_INTO_MIX_V = False
 # head's rows and by the one that owned its token's outliers for ALL heads; since a workgroup takes the outliers of its
 # own heads only, it wins at every length (profiles/r03_b_fused_softmax.txt: 128K 6.12 -> 5.98 ms/step).  Env: A/B runs.
 FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", str(1 << 62)))
-# KVQ_MIX_AFFINE=1: the constant-table p.V kernel (kvq_mix_va.hip: the per-token rows are affine images of QuantV.lut) instead
-# of the per-row kernel.  Measured at 128K nuq4 (profiles/r04_mixva_*): 72 us without outlier entries, 91 - 107 us with them
-# (per-row kernel: 87) -- its dense loop is bound by the HBM stream and the outlier phase, not by the look-ups it saves.
-MIX_PER_ROW = os.environ.get("KVQ_MIX_AFFINE", "0") != "1"
 # One kernel for q.K^T + softmax + p.V per 256-token tile and a merge (kvq_fused_decode.hip: kvq_fused_attend) instead of
 # the score / p.V kernel pair.  Measured (profiles/r04_fused_decode.txt): slower at 32K (one tile per workgroup leaves
 # half the chip idle), equal at 128K, 3 % slower at 256K, 3.7 % FASTER at 1M (several generations of workgroups: K phases
@@ -599,7 +604,8 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
     if (ONE_CALL_PER_LAYER or compact) and kpos == vpos and (sink_scores is None or sinks is not None):
         # the whole launch sequence from one library call (kvq_decode_step): the five Python / ctypes round trips of
         # the path below cost ~78 us of host time per layer, as much as the GPU needs for a 4K-token cache
-        key = (id(vc), getattr(vc, "_tables_version", 0), vc.reference_tie_quirk, vc.norm, kc.norm, kc.compact, vc.compact)
+        key = (id(vc), getattr(vc, "_tables_version", 0), vc.reference_tie_quirk, vc.norm, kc.norm, kc.compact, vc.compact,
+               kc.score_f16_pair)
         cached = getattr(kc, "_step_layer", None)
         if cached is None or cached[0] != key:
             cached = (key,) + ops.make_layer(kc, vc, table, lut_off)
@@ -609,7 +615,7 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         L = kpos + 1
         fuse = FUSE_SOFTMAX_INTO_MIX_V or L <= FUSE_SOFTMAX_UP_TO
         fused = FUSED_ATTEND if FUSED_ATTEND is not None else (bits == 4 and L >= FUSED_ATTEND_FROM)
-        mode = (3 if fused else (2 if MIX_PER_ROW else 1)) if fuse else 0
+        mode = (3 if fused else 1) if fuse else 0
         ops.decode_step(cached[1], kpos, q, k, v, out, mode, sinks, v_sink, sink_probs)
         kc.klen += 1
         vc.vlen += 1
@@ -628,8 +634,7 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         sink_probs = ops.score_k_mix_v(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
                                        kc.outliers, kc.outlier_indices, inv, vc.vcache, out,
                                        vc.mix_table(), vc.outliers, vc.outlier_indices, sink_scores, kc.outliers_t,
-                                       kc.outlier_indices_t, v_sink,
-                                       None if (MIX_PER_ROW or vc.mix_table() is not vc.lookup_table) else vc.lut)
+                                       kc.outlier_indices_t, v_sink, f16_pair=kc.bits == 3 and kc.score_f16_pair)
         return out, sink_probs
     probs, sink_probs = ops.score_k_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, kc.first_few_fp16, ws,
                                             kc.outliers, kc.outlier_indices, inv, sink_scores,

@@ -30,7 +30,7 @@ static StepPlan plan_step(int bits, int H, int hd, int64_t L) {
   p.parts_off = p.score_ws;
   p.parts_b = align256((size_t)H * (p.n_parts > 0 ? p.n_parts : 1) * 8);
   p.mix_off = p.parts_off + p.parts_b;
-  p.mix_b = align256(kvq_mix_v_affine_workspace_bytes(bits, H, hd, L));   // (>= kvq_mix_v_workspace_bytes)
+  p.mix_b = align256(kvq_mix_v_workspace_bytes(bits, 1, H, hd, L));
   p.scores_off = p.mix_off + p.mix_b;
   p.scores_b = align256((size_t)H * L * 4);
   {   // (the fused kernel keeps its tile slabs and statistics where the other routes keep the scores)
@@ -127,9 +127,10 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
     return rc;
   }
   record(0, st);
-  rc = kvq_score_k_prepared_softmax(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta, ly->pos_offset,
-                                    ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws, p.score_ws, inv,
-                                    parts, p.n_parts, stream);
+  rc = kvq_score_k_prepared_softmax_ex(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta,
+                                       ly->pos_offset, ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws,
+                                       p.score_ws, inv, parts, p.n_parts,
+                                       (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) ? KVQ_SCORE_F16_PAIR_TABLES : 0, stream);
   record(1, st);
   if (rc) return rc;
   const float *vrows = ly->v_mix_rows ? ly->v_mix_rows : ly->vlut_rows;
@@ -137,12 +138,9 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
   if (fuse_softmax) {
     // (event 2 goes behind the small softmax-merge launch, in front of the p.V kernel: kvq_step_mark_pv below)
     mark2_pending = true;
-    // the affine form reads ONE constant table: the sorted codebook the rows are images of (fuse_softmax == 2, or rows
-    // of another table -- Q-Norm at 2 bit: the per-row kernel)
-    const float *vtable = (fuse_softmax >= 2 || ly->v_mix_rows) ? nullptr : ly->vlut_sorted;   // (3 not taken: as 2)
-    rc = kvq_mix_v_softmax_affine(bits, scores, parts, p.n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs,
-                                  ly->vmat, out, vrows, vtable, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0,
-                                  ws + p.mix_off, p.mix_b, stream);
+    rc = kvq_mix_v_softmax(bits, scores, parts, p.n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs, ly->vmat,
+                           out, vrows, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0, ws + p.mix_off, p.mix_b,
+                           stream);
     if (mark2_pending) { mark2_pending = false; record(2, st); }   // (a route that does not pass the mark: the whole call)
     record(3, st);
     return rc;

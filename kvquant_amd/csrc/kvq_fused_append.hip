@@ -468,8 +468,9 @@ struct PrologueArgs {
   const float *klut;       // [H][128][N]: source of the score tables (k.lut, or the Q-Norm table at 2 bit)
   const void *q;           // [H][128] fp32 or fp16
   int q_is_half;
-  unsigned char *tab;      // score workspace: tables, then q as fp32
+  unsigned char *tab;      // score workspace: tables, then q as fp32, then (3 bit) the pair-sum images
   float *q32;
+  unsigned char *pair_tab;
   int H;
   // fp16 attention-sink tokens (optional): scaled scores q . k_sink of head h by the head's table workgroup -- the
   // reference's torch.matmul(query_states, key_states_fp16) / sqrt(d) (ML:1950-1962): fp32 accumulation, the fp16
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(kSelThreads) void decode_prologue_kernel(PrologueAr
   } else {
     const int h = (int)blockIdx.x - 2;
     quantize_head<BITS>(P.k, h);
-    lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.H, h, 0);
+    lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.pair_tab, P.H, h, 0);
     if (P.k_sink != nullptr && (int)threadIdx.x < P.n_sink) {
       const int i = threadIdx.x;
       float acc = 0.f;
@@ -722,6 +723,7 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
   P.tab = reinterpret_cast<unsigned char *>(score_workspace);
   const size_t tabb = bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
   P.q32 = reinterpret_cast<float *>(P.tab + (size_t)H * tabb);
+  P.pair_tab = bits == 3 ? P.tab + ktab_pair_offset<3>(1, H) : nullptr;
   P.H = H;
   P.k_sink = nullptr;
   P.sink_scores = nullptr;

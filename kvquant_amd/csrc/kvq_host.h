@@ -22,7 +22,7 @@ inline int check_launch() {
 int pack_k_codes(int bits, int32_t *mat, const float *lut, const float *x, const float *lo, const float *hi, int H,
                  int hd, int64_t S, int64_t max_len, int64_t col0, hipStream_t st);
 
-// kvq_mix_v.hip: the launches around the p.V kernels that kvq_mix_va.hip shares
+// kvq_mix_v.hip: the launches around the p.V kernels (shared with tools/experiments/kvq_mix_va.hip)
 int launch_mix_reduce(const float *partial, float *mul, int n_ranges, int q_len, int C, int accumulate, hipStream_t st);
 int launch_softmax_merge(const float *parts, int n_parts, const void *sink, void *sink_probs, int n_sink, float *mz,
                          const void *v_sink, float *sink_out, int H, hipStream_t st);

@@ -23,10 +23,34 @@ __device__ __forceinline__ float ld_act(const void *p, int64_t i, int is_half) {
   return is_half ? __half2float(reinterpret_cast<const __half *>(p)[i]) : reinterpret_cast<const float *>(p)[i];
 }
 
-// workspace layout of kvq_score_k: [q_len*H tables of BUF_B bytes][q_len*H*128 floats: q as fp32]
+// 3 bit: PAIR-SUM image of one head's codebook in fp16 (round 5).  The two channels of a rotation pair, k_lo = 32r+i and
+// k_hi = k_lo + 64, share (cos, sin), so their two look-ups and two packed FMAs collapse into ONE look-up indexed by both
+// codes and one v_dot2_f32_f16 against the lane's half2 (cos, sin):
+//   P[((i*2 + r)*64 + (c_lo | c_hi << 3))] = half2(a*q[k_lo] + b*q[k_hi],  a*q[k_hi] - b*q[k_lo]),  a = L[k_lo][c_lo], b = L[k_hi][c_hi]
+// 64 entries x 4 B per (pair, role) = 16 KB per head (the fp32 image of 4 bit: 16 KB; a 4-bit pair table would be 64 KB).
+// The sums are formed in fp32 and rounded once to fp16 (2^-11 relative): scores agree with the fp32 path to ~1e-4 of the
+// row's largest score (bar: 1e-3, BASELINE.json; the reference rounds the score itself to fp16, modeling_llama.py:873).
+struct KTabPair3 {
+  static constexpr int PAIR_B = 64 * 4;             // one (pair, role)
+  static constexpr int BUF_B = 32 * 2 * PAIR_B;     // one head: 16 KB
+};
+// does this width keep a pair-sum image next to the fp32 one?
 template <int BITS>
-__device__ __forceinline__ size_t ktab_q_offset(int q_len, int H) {
+struct KTabHasPair { static constexpr bool value = BITS == 3; };
+
+// workspace layout of kvq_score_k: [q_len*H tables of BUF_B bytes][q_len*H*128 floats: q as fp32]
+// [3 bit: q_len*H pair-sum images of KTabPair3::BUF_B bytes]
+template <int BITS>
+__host__ __device__ __forceinline__ size_t ktab_q_offset(int q_len, int H) {
   return (size_t)q_len * H * KTab<BITS>::BUF_B;
+}
+template <int BITS>
+__host__ __device__ __forceinline__ size_t ktab_pair_offset(int q_len, int H) {
+  return ktab_q_offset<BITS>(q_len, H) + (size_t)q_len * H * kHeadDim * sizeof(float);
+}
+template <int BITS>
+__host__ __device__ __forceinline__ size_t ktab_total_bytes(int q_len, int H) {
+  return ktab_pair_offset<BITS>(q_len, H) + (KTabHasPair<BITS>::value ? (size_t)q_len * H * KTabPair3::BUF_B : 0);
 }
 
 // builds the image of head h / query row b in global memory (L2-resident: H*16 KB) and the fp32 copy
@@ -34,7 +58,8 @@ __device__ __forceinline__ size_t ktab_q_offset(int q_len, int H) {
 template <int BITS>
 __device__ __forceinline__ void lutq_prep_head(const float *__restrict__ lut, const void *__restrict__ q,
                                                int q_is_half, unsigned char *__restrict__ tab,
-                                               float *__restrict__ q32, int H, int h, int b) {
+                                               float *__restrict__ q32, unsigned char *__restrict__ pair_tab, int H,
+                                               int h, int b) {
   constexpr int N = Fmt<BITS>::kN;
   const float *lh = lut + (int64_t)h * kHeadDim * N;
   const int64_t qoff = ((int64_t)b * H + h) * kHeadDim;
@@ -52,14 +77,29 @@ __device__ __forceinline__ void lutq_prep_head(const float *__restrict__ lut, co
     d[0] = make_float4(l4.x * qa, l4.x * qb, l4.y * qa, l4.y * qb);
     d[1] = make_float4(l4.z * qa, l4.z * qb, l4.w * qa, l4.w * qb);
   }
+  if constexpr (KTabHasPair<BITS>::value) {
+    // the pair-sum image (KTabPair3): 4096 entries per head
+    if (pair_tab == nullptr) return;
+    unsigned char *pdst = pair_tab + ((int64_t)b * H + h) * KTabPair3::BUF_B;
+    for (int e = threadIdx.x; e < 32 * 2 * 64; e += blockDim.x) {
+      const int idx = e & 63, ir = e >> 6;           // ir = i*2 + r
+      const int i = ir >> 1, r = ir & 1;
+      const int k_lo = 32 * r + i, k_hi = k_lo + 64;
+      const float a = lh[k_lo * N + (idx & 7)], bb = lh[k_hi * N + (idx >> 3)];
+      const float q_lo = ld_act(q, qoff + k_lo, q_is_half), q_hi = ld_act(q, qoff + k_hi, q_is_half);
+      const __half2 v = __floats2half2_rn(fmaf(a, q_lo, bb * q_hi), fmaf(a, q_hi, -(bb * q_lo)));
+      reinterpret_cast<__half2 *>(pdst)[e] = v;
+    }
+  }
 }
 
 
 template <int BITS>
 __global__ __launch_bounds__(256) void lutq_prep_kernel(const float *__restrict__ lut, const void *__restrict__ q,
                                                         int q_is_half, unsigned char *__restrict__ tab,
-                                                        float *__restrict__ q32, int H) {
-  lutq_prep_head<BITS>(lut, q, q_is_half, tab, q32, H, blockIdx.x, blockIdx.y);
+                                                        float *__restrict__ q32, unsigned char *__restrict__ pair_tab,
+                                                        int H) {
+  lutq_prep_head<BITS>(lut, q, q_is_half, tab, q32, pair_tab, H, blockIdx.x, blockIdx.y);
 }
 
 }  // namespace kvq

@@ -47,14 +47,14 @@
 
 namespace kvq {
 
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false, bool PAIR = false>
 __global__ __launch_bounds__(NWAVES * 64, 4)
 void score_k_kernel(ScoreKArgs a) {
-  using G = KGeom<BITS, SPARSE, NWAVES, TRANSPOSED>;
+  using G = KGeom<BITS, SPARSE, NWAVES, TRANSPOSED, PAIR>;
   constexpr int T = G::T, NT = G::NT, SCS = G::SCS;
   // static LDS: every table offset in the tile body is a compile-time constant that folds into ds immediates
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM_B];
-  const KTile kt = score_k_tile<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT>(a, smem);
+  const KTile kt = score_k_tile<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT, PAIR>(a, smem);
   if constexpr (SPARSE) {
     float *sc = reinterpret_cast<float *>(smem + G::SC_OFF);
     const int tid = threadIdx.x;
@@ -167,14 +167,14 @@ static int pick_groups(int H, int64_t tiles, int q_len, int max_hpg, int slots) 
   return best;
 }
 
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false, bool PAIR = false>
 static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipStream_t st) {
   constexpr int T = NWAVES * 32;
   ScoreKArgs a = a0;
   const int64_t full_tiles = a.L / T;
   const int rem = (int)(a.L % T);
   const int max_hpg = SPARSE ? kSparseHpg : 1 << 30;
-  static const int slots = workgroup_slots(score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT>, NWAVES * 64, 16 / NWAVES);
+  static const int slots = workgroup_slots(score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT, PAIR>, NWAVES * 64, 16 / NWAVES);
   a.groups = full_tiles ? pick_groups(a.H, full_tiles, q_len, max_hpg, slots) : 1;
   a.hpg = a.H / a.groups;
   if (full_tiles && a.hpg > max_hpg) return KVQ_EINVAL;   // (no full tile: only the ragged one's head groups exist)
@@ -194,7 +194,7 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
   if (!a.trace) return KVQ_EINVAL;
 #endif
-  score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT><<<grid, block, 0, st>>>(a);
+  score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT, PAIR><<<grid, block, 0, st>>>(a);
   return check_launch();
 }
 
@@ -204,12 +204,24 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
   unsigned char *tab = reinterpret_cast<unsigned char *>(ws);
   float *q32 = reinterpret_cast<float *>(tab + (size_t)q_len * a.H * KTab<BITS>::BUF_B);
   if (!tables_ready) {
-    lutq_prep_kernel<BITS><<<dim3(a.H, q_len), 256, 0, st>>>(lut, q_in, q_is_half, tab, q32, a.H);
+    lutq_prep_kernel<BITS><<<dim3(a.H, q_len), 256, 0, st>>>(
+        lut, q_in, q_is_half, tab, q32, KTabHasPair<BITS>::value ? tab + ktab_pair_offset<BITS>(q_len, a.H) : nullptr, a.H);
     int rc = check_launch();
     if (rc) return rc;
   }
   a.tab = tab;
+  a.tab_pair = KTabHasPair<BITS>::value ? tab + ktab_pair_offset<BITS>(q_len, a.H) : nullptr;
   a.q = q32;   // fp32 copy made by the prep (the sparse phase reads q directly)
+  if constexpr (BITS == 3) {
+    // fp16 pair-sum tables (decode, q_len = 1, mirror formats): half the look-ups (kvq_ktab.h: KTabPair3)
+    if (a.pair && q_len == 1 && a.idx_t != nullptr) {
+      if (a.out_t == nullptr)
+        return a.L >= 16384 ? launch_score<3, true, 8, true, true, true>(a, q_len, theta, st)
+                            : launch_score<3, true, 4, true, true, true>(a, q_len, theta, st);
+      return a.L >= 16384 ? launch_score<3, true, 8, true, false, true>(a, q_len, theta, st)
+                          : launch_score<3, true, 4, true, false, true>(a, q_len, theta, st);
+    }
+  }
   // big tiles (8 waves) once there are enough of them, small tiles for short caches
   if (a.idx_t != nullptr && a.out_t == nullptr) {     // compact mirror
     return a.L >= 16384 ? launch_score<BITS, true, 8, true, true>(a, q_len, theta, st)
@@ -225,8 +237,8 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
   return sparse ? launch_score<BITS, true, 4>(a, q_len, theta, st) : launch_score<BITS, false, 4>(a, q_len, theta, st);
 }
 
-static size_t tab_bytes(int bits) {
-  return bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
+static size_t ws_bytes(int bits, int q_len, int H) {
+  return bits == 4 ? ktab_total_bytes<4>(q_len, H) : (bits == 3 ? ktab_total_bytes<3>(q_len, H) : ktab_total_bytes<2>(q_len, H));
 }
 
 }  // namespace kvq
@@ -242,7 +254,7 @@ int kvq_score_k_head_groups(int H, int64_t tiles, int q_len, int max_heads_per_g
 
 size_t kvq_score_k_workspace_bytes(int bits, int q_len, int H) {
   if (bits < 2 || bits > 4 || q_len <= 0 || H <= 0) return 0;
-  return (size_t)q_len * H * (tab_bytes(bits) + kHeadDim * sizeof(float));
+  return ws_bytes(bits, q_len, H);
 }
 
 static int score_entry(int bits, const void *q, int q_is_half, int tables_ready, const int32_t *mat, float *mul,
@@ -250,7 +262,7 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
                        int pos_offset, const float *outliers, const int32_t *outlier_idx, int n_out, int accumulate,
                        void *workspace, size_t workspace_bytes, void *stream, float *sm_parts = nullptr,
                        float sm_inv = 0.f, int sm_nparts = 0, const float *outliers_t = nullptr,
-                       const int32_t *idx_t = nullptr) {
+                       const int32_t *idx_t = nullptr, int pair = 0) {
   if ((!q && !tables_ready) || !mat || !mul || !lut || q_len <= 0 || H <= 0 || hd != kHeadDim || L < 0 ||
       L > max_len || bits < 2 || bits > 4)
     return KVQ_EINVAL;
@@ -279,6 +291,8 @@ static int score_entry(int bits, const void *q, int q_is_half, int tables_ready,
   a.n_out = n_out;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.accumulate = accumulate;
+  a.pair = pair;
+  a.tab_pair = nullptr;
   a.sm_parts = sm_parts;
   a.sm_inv = sm_inv;
   a.sm_nparts = sm_nparts;
@@ -320,11 +334,23 @@ int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul, const
                                  const float *outliers_t, const int32_t *outlier_idx_t, void *workspace,
                                  size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts, int n_parts,
                                  void *stream) {
+  return kvq_score_k_prepared_softmax_ex(bits, mat, mul, lut, H, hd, L, max_len, rope_theta, pos_offset, outliers,
+                                         outlier_idx, n_out, outliers_t, outlier_idx_t, workspace, workspace_bytes,
+                                         inv_sqrt_hd, softmax_parts, n_parts, 0, stream);
+}
+
+int kvq_score_k_prepared_softmax_ex(int bits, const int32_t *mat, float *mul, const float *lut, int H, int hd,
+                                    int64_t L, int64_t max_len, float rope_theta, int pos_offset,
+                                    const float *outliers, const int32_t *outlier_idx, int n_out,
+                                    const float *outliers_t, const int32_t *outlier_idx_t, void *workspace,
+                                    size_t workspace_bytes, float inv_sqrt_hd, float *softmax_parts, int n_parts,
+                                    int flags, void *stream) {
   if (!softmax_parts || (!outliers && !outlier_idx_t) || n_parts != kvq_score_k_softmax_parts(bits, L, 1))
     return KVQ_EINVAL;
   return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset,
                      outlier_idx_t ? nullptr : outliers, outlier_idx_t ? nullptr : outlier_idx, n_out, 0, workspace,
-                     workspace_bytes, stream, softmax_parts, inv_sqrt_hd, n_parts, outliers_t, outlier_idx_t);
+                     workspace_bytes, stream, softmax_parts, inv_sqrt_hd, n_parts, outliers_t, outlier_idx_t,
+                     (flags & KVQ_SCORE_F16_PAIR_TABLES) ? 1 : 0);
 }
 
 }  // extern "C"

@@ -24,6 +24,7 @@ struct ScoreKArgs {
   const uint32_t *mat;     // [H][WPH][max_len]
   float *mul;              // [q_len][H][L]
   const unsigned char *tab;  // [q_len][H][TAB_B] pre-multiplied codebook images (workspace)
+  const unsigned char *tab_pair;  // 3 bit, PAIR variants: [H][KTabPair3::BUF_B] fp16 pair-sum images (kvq_ktab.h)
   const float *outliers;   // [max_len][n_out] or null
   const int32_t *idx;
   const float *out_t;      // token-contiguous mirror [n_out][max_len] (TRANSPOSED variant) or null
@@ -39,6 +40,7 @@ struct ScoreKArgs {
   int n_out;
   uint32_t n_out_magic;    // ceil(2^32 / n_out): e / n_out == umulhi(e, magic) for e < 2^32 / n_out
   int accumulate;
+  int pair;                // 3 bit + mirror: read the fp16 pair-sum tables (PAIR variants)
   // optional fusion of the first softmax pass (sparse variant, q_len = 1, accumulate = 0): per (head, tile)
   // max and sum of exp of the SCALED scores, [H][sm_nparts][2]
   float *sm_parts;
@@ -94,6 +96,15 @@ __device__ __forceinline__ uint32_t nib_field(const NibSplit &x, uint32_t role, 
   return r;
 }
 
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+// (a & ma) | (b & mb) | role: the pair-index register of the 3-bit PAIR variants
+__device__ __forceinline__ uint32_t pair_merge(uint32_t a, uint32_t b, uint32_t ma, uint32_t mb, uint32_t rolepat) {
+  uint32_t t, r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "s"(ma), "v"(rolepat));
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "s"(mb), "v"(t));
+  return r;
+}
+
 constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse variant (LDS budget: 32 KB score tile)
 
 // SPARSE: fused outlier SpMV.  TRANSPOSED (implies SPARSE): the outliers come from the token-contiguous
@@ -102,11 +113,11 @@ constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse varian
 // COMPACT (implies TRANSPOSED): the mirror holds packed entries -- fp16 residual << 16 | channel, 4 bytes instead of 8 --
 // in idx_t (opt-in format of kvquant_amd's own cache); one load per entry.
 // LDS geometry of a score workgroup (shared with kvq_fused_decode.hip, which runs the same tile body)
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool PAIR = false>
 struct KGeom {
   static constexpr int T = NWAVES * 32;
   static constexpr int NT = NWAVES * 64;
-  static constexpr int TAB_B = KTab<BITS>::BUF_B;
+  static constexpr int TAB_B = PAIR ? KTabPair3::BUF_B : KTab<BITS>::BUF_B;
   static constexpr int SCS = kSparseHpg;
   static constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
   static constexpr int PF = SPARSE ? 2 : 3;
@@ -126,15 +137,18 @@ struct KTile {
 // the LDS tile at KGeom::SC_OFF (complete for the lanes' own rows when this returns; a barrier publishes them to the other
 // waves); the dense variant writes them out itself.
 // (tile_i, h0_i, nh_i): the tile and the head group; score_k_tile below derives them from the block index
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT>
+// PAIR (3 bit, implies TRANSPOSED): fp16 pair-sum tables (KTabPair3) -- one ds_read_b32 + one v_dot2_f32_f16 per TWO codes,
+// half2 (cos, sin) per rotation pair (32 instead of 64 trig registers).
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT, bool PAIR = false>
 __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned char *smem, int tile_i, int h0_i, int nh_i) {
   static_assert(!TRANSPOSED || SPARSE, "the transposed mirror is a sparse variant");
   static_assert(!COMPACT || TRANSPOSED, "packed entries live in the mirror");
+  static_assert(!PAIR || (BITS == 3 && TRANSPOSED), "pair-sum tables: 3 bit, decode (mirror) variants");
   constexpr int N = Fmt<BITS>::kN;
   constexpr int WPH = Fmt<BITS>::kWordsPerHead;
   constexpr int T = NWAVES * 32;
   constexpr int NT = NWAVES * 64;
-  constexpr int TAB_B = KTab<BITS>::BUF_B;
+  constexpr int TAB_B = PAIR ? KTabPair3::BUF_B : KTab<BITS>::BUF_B;
   constexpr int SCS = kSparseHpg;       // score-tile row stride (token-major; the column is rotated by the
                                         // token so that neither the per-token nor the per-head access conflicts)
   constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
@@ -161,7 +175,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   // q of the group's heads for the sparse phase: 16 KB.  With 4-bit tables it aliases table buffer 1, which
   // is first written (by the DMA for the second head) after the sparse phase; smaller tables leave room.
   constexpr int QL_B = SPARSE ? kSparseHpg * kHeadDim * 4 : 0;
-  static_assert(PF * TAB_B + SC_B + QL_B == KGeom<BITS, SPARSE, NWAVES, TRANSPOSED>::SMEM_B, "KGeom");
+  static_assert(PF * TAB_B + SC_B + QL_B == KGeom<BITS, SPARSE, NWAVES, TRANSPOSED, PAIR>::SMEM_B, "KGeom");
   unsigned char *lutq = smem;                                                    // [PF][TAB_B]
   float *sc = reinterpret_cast<float *>(smem + PF * TAB_B);                      // [T][SCS]
   float *ql = reinterpret_cast<float *>(smem + PF * TAB_B + SC_B);   // [hpg][128]
@@ -199,7 +213,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   const int h0 = __builtin_amdgcn_readfirstlane(h0_i);
   const int b = blockIdx.z;
   const float *qb = a.q + (int64_t)b * a.H * kHeadDim;
-  const unsigned char *tabb = a.tab + ((int64_t)b * a.H + h0) * TAB_B;
+  const unsigned char *tabb = (PAIR ? a.tab_pair : a.tab) + ((int64_t)b * a.H + h0) * TAB_B;
 
   // table of head `hh` -> LDS buffer `buf` (linear copy, lane*16 bytes per instruction)
   auto issue_table = [&](int hh, int buf) {
@@ -395,15 +409,20 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   }
 
   // RoPE angles of this lane's token for its 32 rotation pairs (KCU:3083, 3122-3123)
-  f32x2 cs[32];   // (cos, sin)
+  f32x2 cs[PAIR ? 1 : 32];   // (cos, sin)
+  h16x2 csh[PAIR ? 32 : 1];  // PAIR: the same as half2
   const float posf = (float)((int)tc + a.pos_offset);
   static_for<0, 32>([&](auto I) {
     constexpr int i = decltype(I)::value;
     const float ang = theta_of(role * 32 + i) * posf;
     float sn, c;
     sincos_rev(ang, sn, c);
-    cs[i].x = c;
-    cs[i].y = sn;
+    if constexpr (PAIR) {
+      csh[i] = h16x2{(_Float16)c, (_Float16)sn};
+    } else {
+      cs[i].x = c;
+      cs[i].y = sn;
+    }
   });
 
   // One entry of this lane's token (transposed mirror).  The lane owns its token's row of the score tile;
@@ -449,6 +468,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   const uint32_t role_lo = role ? 0x10101010u : 0u, role_hi = role ? 0x01010100u : 0u, role_u = (uint32_t)role;   // 4 bit: nib_split
   const uint32_t three = __builtin_amdgcn_readfirstlane(3);
   const uint32_t rolebytes = (uint32_t)role * N * 8;    // generic
+  const uint32_t role_pa = role ? 0x00100100u : 0u, role_pb = role ? 0x04004000u : 0u, role_8 = role ? 0x100u : 0u;   // PAIR
 
   auto head = [&](auto BUF, int hh) {
     constexpr int buf = decltype(BUF)::value;          // register set and table buffer of this head
@@ -506,8 +526,61 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
     f32x2 acc4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     // (JIT: a wave without tokens -- ragged last tile -- decodes its clamped token like the others, so that every wave
     //  issues the same operations per head; its results are dropped below)
+    float accp[4] = {0.f, 0.f, 0.f, 0.f};          // PAIR: fp32 accumulators of the v_dot2 chain
     if ((wact || JIT) && !(KVQ_ABL & 64)) {
-    if constexpr (BITS == 4) {
+    if constexpr (PAIR) {
+      // The 3-bit fields of the two 96-bit streams (channels 32r.. in wlo, 64+32r.. in whi) are merged pairwise into 6-bit
+      // indices c_lo | c_hi << 3, planted at bits 2 + 6k of a register with the role bit above every second one, so that a
+      // single cut of 9 bits is the variable part of the look-up address, index * 4 + role * 256 (KTabPair3).  Word w holds
+      // fields g = 0..9 of the stream from bit w on (pair i = 11w + g); the two straddling fields, i = 10 and 21, are
+      // assembled from two words.
+      const unsigned char *tp = lutq + buf * TAB_B;
+      static_for<0, 3>([&](auto WI) {
+        constexpr int w = decltype(WI)::value;
+        static_for<0, 2>([&](auto PI) {
+          constexpr int par = decltype(PI)::value;          // 0: fields g = 0, 2, .., 8;  1: g = 1, 3, .., 9
+          constexpr int sa = 2 - w - 3 * par;               // net left shift that puts c_lo of field g = 2k + par at bit 2 + 6k
+          constexpr int sb = 5 - w - 3 * par;               // ... and c_hi at bit 5 + 6k
+          uint32_t A2;
+          if constexpr (sa >= 0) A2 = wlo[w] << sa;
+          else A2 = wlo[w] >> (-sa);
+          const uint32_t B5 = whi[w] << sb;
+          const uint32_t xa = pair_merge(A2, B5, 0x1C01C01Cu, 0xE00E00E0u, role_pa);   // k = 0, 2, 4 (+ role bits 8, 20)
+          const uint32_t xb = pair_merge(A2, B5, 0x00700700u, 0x03803800u, role_pb);   // k = 1, 3 (+ role bits 14, 26)
+          uint32_t ad[5];
+          ad[0] = xa & 0x1ffu;
+          asm("v_bfe_u32 %0, %1, 6, 9" : "=v"(ad[1]) : "v"(xb));
+          asm("v_bfe_u32 %0, %1, 12, 9" : "=v"(ad[2]) : "v"(xa));
+          asm("v_bfe_u32 %0, %1, 18, 9" : "=v"(ad[3]) : "v"(xb));
+          asm("v_alignbit_b32 %0, %1, %2, 24" : "=v"(ad[4]) : "v"(role_u), "v"(xa));
+          h16x2 v[5];
+          static_for<0, 5>([&](auto KI) {
+            constexpr int k = decltype(KI)::value;
+            constexpr int i = 11 * w + 2 * k + par;
+            v[k] = *reinterpret_cast<const h16x2 *>(tp + i * 2 * KTabPair3::PAIR_B + ad[k]);
+          });
+          static_for<0, 5>([&](auto KI) {
+            constexpr int k = decltype(KI)::value;
+            constexpr int i = 11 * w + 2 * k + par;
+            accp[k & 3] = __builtin_amdgcn_fdot2(v[k], csh[i], accp[k & 3], false);
+          });
+        });
+      });
+      // the straddling fields: i = 10 (bits 30, 31 of word 0 + bit 0 of word 1), i = 21 (bit 31 of word 1 + bits 0, 1 of word 2)
+      {
+        uint32_t x10, y10, x21, y21;
+        asm("v_alignbit_b32 %0, %1, %2, 30" : "=v"(x10) : "v"(wlo[1]), "v"(wlo[0]));
+        asm("v_alignbit_b32 %0, %1, %2, 30" : "=v"(y10) : "v"(whi[1]), "v"(whi[0]));
+        asm("v_alignbit_b32 %0, %1, %2, 31" : "=v"(x21) : "v"(wlo[2]), "v"(wlo[1]));
+        asm("v_alignbit_b32 %0, %1, %2, 31" : "=v"(y21) : "v"(whi[2]), "v"(whi[1]));
+        const uint32_t a10 = ((((y10 & 7u) << 3) | (x10 & 7u)) << 2) | role_8;
+        const uint32_t a21 = ((((y21 & 7u) << 3) | (x21 & 7u)) << 2) | role_8;
+        const h16x2 v10 = *reinterpret_cast<const h16x2 *>(tp + 10 * 2 * KTabPair3::PAIR_B + a10);
+        const h16x2 v21 = *reinterpret_cast<const h16x2 *>(tp + 21 * 2 * KTabPair3::PAIR_B + a21);
+        accp[1] = __builtin_amdgcn_fdot2(v10, csh[10], accp[1], false);
+        accp[2] = __builtin_amdgcn_fdot2(v21, csh[21], accp[2], false);
+      }
+    } else if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         // the words split into low / high nibbles with the role bit next to each (nib_field cuts code*8 + role*128 out)
@@ -583,7 +656,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
       }
     }   // wact
     const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-    float res = acc.x + acc.y;
+    float res = PAIR ? (accp[0] + accp[1]) + (accp[2] + accp[3]) : acc.x + acc.y;
     res += __shfl_xor(res, 32);
 #if KVQ_TRACE
     asm volatile("" :: "v"(res));
@@ -717,11 +790,11 @@ __device__ __forceinline__ void score_k_block_map(const ScoreKArgs &a, int &tile
   }
 }
 
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT, bool PAIR = false>
 __device__ __forceinline__ KTile score_k_tile(const ScoreKArgs &a, unsigned char *smem) {
   int tile_i, h0_i, nh_i;
   score_k_block_map(a, tile_i, h0_i, nh_i);
-  return score_k_tile_at<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT>(a, smem, tile_i, h0_i, nh_i);
+  return score_k_tile_at<BITS, SPARSE, NWAVES, TRANSPOSED, COMPACT, PAIR>(a, smem, tile_i, h0_i, nh_i);
 }
 
 }  // namespace kvq

@@ -134,9 +134,9 @@ int kvq_score_k_tables(int bits, const void *q, int q_is_half, const float *lut,
   unsigned char *tab = reinterpret_cast<unsigned char *>(workspace);
   hipStream_t st = (hipStream_t)stream;
   switch (bits) {
-    case 4: lutq_prep_kernel<4><<<dim3(H, 1), 256, 0, st>>>(lut, q, q_is_half, tab, reinterpret_cast<float *>(tab + (size_t)H * KTab<4>::BUF_B), H); break;
-    case 3: lutq_prep_kernel<3><<<dim3(H, 1), 256, 0, st>>>(lut, q, q_is_half, tab, reinterpret_cast<float *>(tab + (size_t)H * KTab<3>::BUF_B), H); break;
-    default: lutq_prep_kernel<2><<<dim3(H, 1), 256, 0, st>>>(lut, q, q_is_half, tab, reinterpret_cast<float *>(tab + (size_t)H * KTab<2>::BUF_B), H); break;
+    case 4: lutq_prep_kernel<4><<<dim3(H, 1), 256, 0, st>>>(lut, q, q_is_half, tab, reinterpret_cast<float *>(tab + ktab_q_offset<4>(1, H)), KTabHasPair<4>::value ? tab + ktab_pair_offset<4>(1, H) : nullptr, H); break;
+    case 3: lutq_prep_kernel<3><<<dim3(H, 1), 256, 0, st>>>(lut, q, q_is_half, tab, reinterpret_cast<float *>(tab + ktab_q_offset<3>(1, H)), KTabHasPair<3>::value ? tab + ktab_pair_offset<3>(1, H) : nullptr, H); break;
+    default: lutq_prep_kernel<2><<<dim3(H, 1), 256, 0, st>>>(lut, q, q_is_half, tab, reinterpret_cast<float *>(tab + ktab_q_offset<2>(1, H)), KTabHasPair<2>::value ? tab + ktab_pair_offset<2>(1, H) : nullptr, H); break;
   }
   return check_launch();
 }

@@ -432,18 +432,20 @@ def score_k_prepared(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers=Non
 
 
 def score_k_prepared_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, outlier_indices, inv_sqrt_hd,
-                             n_parts, outliers_t=None, outlier_indices_t=None):
+                             n_parts, outliers_t=None, outlier_indices_t=None, f16_pair=False):
     """sparse score kernel (tables already in `ws`, accumulate = 0) that also writes the per-(head, tile)
-    softmax partials; returns the partials buffer (a workspace: consume it before the next call)."""
+    softmax partials; returns the partials buffer (a workspace: consume it before the next call).
+    f16_pair (3 bit, with the mirror): read the fp16 pair-sum tables (include/kvq.h: KVQ_SCORE_F16_PAIR_TABLES)."""
     H, hd, max_len = _cache_dims(mat, bits)
     with _Dev(mat):
         parts = _workspace(mat.device, H * n_parts * 8, slot="softmax")
-        _lib.check(_L().kvq_score_k_prepared_softmax(
+        _lib.check(_L().kvq_score_k_prepared_softmax_ex(
             bits, _i(mat, "mat"), _f(mul, "mul"), _f(lut, "lookup_table"), H, hd, int(L), max_len, float(theta),
             int(pos_offset), _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outliers.shape[1],
             *_mirror(outliers_t, outlier_indices_t, outliers.shape[1] // 2, max_len),
-            ws.data_ptr(), ws.numel(), float(inv_sqrt_hd), parts.data_ptr(), n_parts, _stream()),
-            "kvq_score_k_prepared_softmax")
+            ws.data_ptr(), ws.numel(), float(inv_sqrt_hd), parts.data_ptr(), n_parts,
+            _lib.SCORE_F16_PAIR_TABLES if f16_pair else 0, _stream()),
+            "kvq_score_k_prepared_softmax_ex")
     return parts
 
 
@@ -485,7 +487,7 @@ def score_k_softmax(bits, mat, mul, lut, L, theta, pos_offset, ws, outliers, out
 
 def score_k_mix_v(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices, inv_sqrt_hd,
                   vmat, out, vlut_rows, voutliers, voutlier_indices, sink_scores=None, koutliers_t=None,
-                  koutlier_indices_t=None, v_sink=None, vtable=None):
+                  koutlier_indices_t=None, v_sink=None, f16_pair=False):
     """q.K^T (tables already in `ws`) -> softmax -> p.V of one decode token in two streaming launches + the slab
     reduce: the score kernel writes raw scores and per-tile softmax partials, the p.V kernel normalises on the way
     (kvq_mix_v_softmax).  scores [1, H, L] scratch, out f32 [1, H, hd].  Returns sink_probs (f16 [H, n_sink]) or None."""
@@ -498,37 +500,35 @@ def score_k_mix_v(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers,
               accumulate=v_sink is not None)
         return sink_probs
     parts = score_k_prepared_softmax(bits, kmat, scores, klut, L, theta, pos_offset, ws, koutliers, koutlier_indices,
-                                     inv_sqrt_hd, n_parts, koutliers_t, koutlier_indices_t)
+                                     inv_sqrt_hd, n_parts, koutliers_t, koutlier_indices_t, f16_pair=f16_pair)
     return mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, vmat, out, vlut_rows, L, voutliers,
-                         voutlier_indices, sink_scores, v_sink, vtable)
+                         voutlier_indices, sink_scores, v_sink)
 
 
 def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows, L, outliers, outlier_indices,
-                  sink_scores=None, v_sink=None, table=None):
-    """kvq_mix_v_softmax[_affine]: raw scores [1, H, L] + the score kernel's softmax partials -> mul f32 [1, H, hd]
+                  sink_scores=None, v_sink=None):
+    """kvq_mix_v_softmax: raw scores [1, H, L] + the score kernel's softmax partials -> mul f32 [1, H, hd]
     (overwritten; with v_sink f16 [H, n_sink, 128] it includes the sink tokens' share); returns sink_probs
-    (f16 [H, n_sink]) or None.  table (f32 [2^bits], the sorted codebook every row of lut_rows is an affine image of):
-    the constant-table kernel (kvq_mix_va.hip); None: the per-row kernel."""
+    (f16 [H, n_sink]) or None."""
     H, hd, max_len = _cache_dims(mat, bits)
     n_sink = 0 if sink_scores is None else sink_scores.shape[1]
     sink_probs = None if n_sink == 0 else torch.empty_like(sink_scores)
     with _Dev(mat):
-        nbytes = _L().kvq_mix_v_affine_workspace_bytes(bits, H, hd, int(L))
+        nbytes = _L().kvq_mix_v_workspace_bytes(bits, 1, H, hd, int(L))
         wsv = _workspace(mat.device, nbytes)
         # room for the probabilities of the library's two-pass route: always handed over, so that the shapes its
         # streaming kernel does not take (unaligned rows or tables, H > 128, more than 2^31 packed words, ...) fall back
         # inside the library whatever its predicate is -- the two checks cannot drift apart (H * L * 4 bytes, cached)
         probs = _workspace(mat.device, H * int(L) * 4, slot="probs")
-        _lib.check(_L().kvq_mix_v_softmax_affine(
+        _lib.check(_L().kvq_mix_v_softmax(
             bits, _f(scores, "scores"), parts.data_ptr(), n_parts, float(inv_sqrt_hd),
             None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"),
             None if n_sink == 0 else sink_probs.data_ptr(), n_sink,
             None if v_sink is None else _chk(v_sink, torch.float16, "v_sink"),
             None if probs is None else probs.data_ptr(),
-            _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), None if table is None else _f(table, "lut"),
-            H, hd, int(L), max_len,
+            _i(mat, "mat"), _f(mul, "mul"), _f(lut_rows, "lookup_table"), H, hd, int(L), max_len,
             _fo(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), outlier_indices.shape[1], 0,
-            wsv.data_ptr(), wsv.numel(), _stream()), "kvq_mix_v_softmax_affine")
+            wsv.data_ptr(), wsv.numel(), _stream()), "kvq_mix_v_softmax")
     return sink_probs
 
 
@@ -613,7 +613,8 @@ def make_layer(kc, vc, table, lut_off):
         None if kc.lut_ends is None else _f(kc.lut_ends, "lut_ends"), None if table is kc.lookup_table else _f(table, "lut_score"),
         _i(vc.vcache, "vcache"), _f(vc.lookup_table, "lookup_table"), _f(vc.lut, "lut"), _fo(vc.outliers, "outliers"),
         _i(vc.outlier_indices, "outlier_indices"), None if vstruct is None else ctypes.pointer(vstruct),
-        None if mix is vc.lookup_table else _f(mix, "lookup_table2"))
+        None if mix is vc.lookup_table else _f(mix, "lookup_table2"),
+        _lib.LAYER_SCORE_F16_PAIR if (kc.bits == 3 and getattr(kc, "score_f16_pair", False)) else 0)
     return ly, (vstruct, table, lut_off, mix)
 
 
