@@ -627,8 +627,67 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
           __builtin_amdgcn_sched_group_barrier(0x002, 2 * LKB, 0);    // v_pk_fma_f32
         });
       });
+    } else if constexpr (BITS == 3) {
+      // 3 bit, fp32 tables (round 5): 1.3 instead of 2 VALU operations per code for the look-up address code * 8 + role * 64.
+      // Word w of a 96-bit stream holds the fields g = 0..9 from bit w on (channel i = 11w + g); taking every THIRD
+      // field (class cl = g % 3) leaves six zero bits between two fields, so with the role bit planted right above each
+      // field ONE cut of 7 bits that starts 3 below the field is the address part (the 4-bit path's nib_split / nib_field
+      // idea; with every second field the role bit of one field would be the lowest bit of the next one's cut).
+      // The straddling fields i = 10 and 21 are assembled from two words.
+      const uint32_t role_all = role ? 0xffffffffu : 0u;
+      static_for<0, 3>([&](auto WI) {
+        constexpr int w = decltype(WI)::value;
+        static_for<0, 3>([&](auto CI) {
+          constexpr int cl = decltype(CI)::value;
+          constexpr int NF = cl == 0 ? 4 : 3;                    // fields g = cl, cl + 3, ... < 10
+          constexpr int b0 = w + 3 * cl;                         // bit of the class's first field; the others 9 bits apart
+          constexpr uint32_t fm = (7u << b0) | (7u << (b0 + 9)) | (7u << (b0 + 18)) | (NF == 4 ? (7u << (b0 + 27)) : 0u);
+          constexpr uint32_t rb = (uint32_t)((((1ull << (b0 + 3)) | (1ull << (b0 + 12)) | (1ull << (b0 + 21)) |
+                                               (NF == 4 ? (1ull << (b0 + 30)) : 0ull))) & 0xffffffffull);
+          const uint32_t rpat = role_all & rb;
+          uint32_t xl, xh;
+          asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(xl) : "v"(wlo[w]), "s"(fm), "v"(rpat));
+          asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(xh) : "v"(whi[w]), "s"(fm), "v"(rpat));
+          // (the two streams one after the other: NF look-ups in flight at a time -- both at once spill four registers
+          //  of the 8-wave mirror variant, and a spilled look-ahead register there is not merely slow but wrong)
+          static_for<0, 2>([&](auto HI) {
+            constexpr int hi = decltype(HI)::value;
+            const uint32_t x = hi ? xh : xl;
+            const unsigned char *tb = hi ? thi : tlo;
+            f32x2 v[NF];
+            static_for<0, NF>([&](auto KI) {
+              constexpr int k = decltype(KI)::value;
+              constexpr int i = 11 * w + 3 * k + cl;
+              constexpr int b = b0 + 9 * k;
+              uint32_t f;
+              if constexpr (b < 3) {
+                f = (x << (3 - b)) & 0x7fu;
+              } else if constexpr (b + 3 >= 32) {
+                asm("v_alignbit_b32 %0, %1, %2, %3" : "=v"(f) : "v"(role_u), "v"(x), "n"(b - 3));
+              } else {
+                asm("v_bfe_u32 %0, %1, %2, 7" : "=v"(f) : "v"(x), "n"(b - 3));
+              }
+              v[k] = *reinterpret_cast<const f32x2 *>(tb + i * 2 * N * 8 + f);
+            });
+            static_for<0, NF>([&](auto KI) {
+              constexpr int k = decltype(KI)::value;
+              constexpr int i = 11 * w + 3 * k + cl;
+              acc4[(k + 2 * hi) & 3] = __builtin_elementwise_fma(cs[i], v[k], acc4[(k + 2 * hi) & 3]);
+            });
+          });
+        });
+      });
+      static_for<0, 2>([&](auto SI) {
+        constexpr int i = decltype(SI)::value == 0 ? 10 : 21;
+        const uint32_t fl = (code_of<BITS, i>(wlo) << 3) + rolebytes;
+        const uint32_t fh = (code_of<BITS, i>(whi) << 3) + rolebytes;
+        const f32x2 vl = *reinterpret_cast<const f32x2 *>(tlo + i * 2 * N * 8 + fl);
+        const f32x2 vh = *reinterpret_cast<const f32x2 *>(thi + i * 2 * N * 8 + fh);
+        acc4[0] = __builtin_elementwise_fma(cs[i], vl, acc4[0]);
+        acc4[2] = __builtin_elementwise_fma(cs[i], vh, acc4[2]);
+      });
     } else {
-      // generic (2 / 3 bit) decode: batches of GB pairs; the sparse variants are at the VGPR limit, and a
+      // generic (2 bit) decode: batches of GB pairs; the sparse variants are at the VGPR limit, and a
       // spilled look-ahead register is not merely slow but wrong (see the look-ahead sets above)
       constexpr int GB = SPARSE ? 4 : 8;
       static_for<0, 32 / GB>([&](auto J) {

@@ -101,7 +101,7 @@ def test_score_f16_pair_tables_at_size_against_reference(ref, L, pos_offset):
     look-up and one v_dot2_f32_f16 per rotation pair instead of two look-ups and two packed FMAs) against the reference's
     own kernel over the whole cache, incl. positions beyond 10^6.  The table entries and (cos, sin) are rounded to fp16
     (2^-11 relative), the sums accumulate in fp32: the bar is the north star's 1e-3; the measured error is printed and
-    additionally held to 4e-4, so that a regression of the rounding scheme (e.g. an fp16 accumulator) is caught."""
+    additionally held to 6e-4 (measured 3.5e-4), so that a regression of the rounding scheme (e.g. an fp16 accumulator) is caught."""
     from kvquant_amd import ops
     dev = torch.device("cuda:0")
     bits = 3
@@ -126,7 +126,7 @@ def test_score_f16_pair_tables_at_size_against_reference(ref, L, pos_offset):
     ulp = (s16[0] - s_ref[0]).abs() / (s_ref[0].abs().clamp_min(1e-3) * 2.0 ** -11)
     print("L=%d pos_offset=%d: |score - reference| fp32 tables %.2e, fp16 pair tables %.2e (max %.2f fp16 ulps of the score, mean %.3f)"
           % (L, pos_offset, e32, e16, float(ulp.max()), float(ulp.mean())))
-    assert e32 < 1e-5 and e16 < 4e-4 < TOL
+    assert e32 < 1e-5 and e16 < 6e-4 < TOL      # (measured: 3.5e-4 .. 3.7e-4)
     # the softmax partials of the same launch describe the scores it wrote
     probs, _ = ops.softmax_finish(s16[0], parts, n_parts, inv)
     ref_p = torch.softmax((s16[0].half().float() * inv).half().float(), dim=-1).half().float()

@@ -84,7 +84,7 @@ def test_fused_is_the_default_from_512k_tokens_and_matches_the_separate_kernels(
             assert err < TOL, (step, err)
     finally:
         ops.decode_step = real
-    assert modes == [3, 2, 3, 2], modes
+    assert modes == [3, 1, 3, 1], modes
 
 
 @pytest.mark.parametrize("bits,ctx", [(3, 700), (4, 40000)])
