@@ -342,27 +342,29 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
 #endif
     }
   };
-  auto sparse_phase_one = [&]() {
-    // ONE unit group (2 / 3 bit at H = 32: every entry of the range belongs to this workgroup).  Round 5: straight-line
-    // code -- all of a block's entries and the raw scores of its tokens are requested together through buffer descriptors
-    // (one 32-bit lane offset per load, no address pairs), every entry is evaluated without control flow (a padding
-    // entry adds 0 into a per-lane dummy accumulator) and nothing of the entry -> (token, head) arithmetic is kept
-    // across the loads.  Same box, 128K nuq3 + 5 sinks: p.V + reduce 93.6 -> 89.3 us (profiles/r05_pv_outlier_phase.txt).
-    // With two unit groups half of the entries a workgroup reads are the other group's: there the branch per entry of
-    // sparse_phase_rows (which skips them) is faster (4 bit: 89 vs 92 us), and windows of the sorted rows (32 of 42
-    // slots from the group's end, the rest in a second pass when some token needs it) are slower still: one workgroup
-    // in four takes the second pass, and the launch waits for the slowest (112 us).
+  // Outlier entries, straight-line form (round 5): the workgroup takes the tokens [ts0, ts1) of its range, ALL their slots,
+  // and adds into the accumulators of the channels [c_lo, c_lo + cn) (heads [hf0, hf0 + HWv)) -- every entry it reads is
+  // its own.  All of a block's entries and the raw scores of its tokens are requested together through buffer
+  // descriptors (one 32-bit lane offset per load, no address pairs), every entry is evaluated without control flow (a
+  // padding entry adds 0 into a per-lane dummy accumulator) and nothing of the entry -> (token, head) arithmetic is kept
+  // across the loads.  Two uses:
+  //  * ONE unit group (2 / 3 bit at H = 32): the whole range, the group's channels.  Same box, 128K nuq3 + 5 sinks:
+  //    p.V + reduce 93.6 -> 89.3 us (profiles/r05_pv_outlier_phase.txt).
+  //  * several unit groups, SPLIT BY TOKENS (a.split; 4 bit at H = 32, long caches): group g takes the g-th share of the
+  //    range's tokens for ALL channels, so that every entry is read once, by one workgroup, in one round of 21 loads per
+  //    lane (sparse_phase_rows: every group reads every entry, two rounds of 24, and skips the other groups' with a branch
+  //    per entry).  The sums for its own channels join its dense partial as before; those for the other groups' channels
+  //    go to EXTRA slabs that the reduce kernel adds like any other (slab n_ranges + range * (G - 1) + j holds, for every
+  //    group x, what group (x - 1 - j) mod G found for x's channels: each extra slab is complete).
+  //    Windows of the channel-sorted rows instead (32 of 42 slots from the group's end, a second pass when some token
+  //    needs it) were measured slower: one workgroup in four takes the second pass and the launch waits for it (112 us).
+  auto sparse_phase_all = [&](int64_t ts0, int64_t ts1, int c_lo, int cn, int hf0, int HWv) {
     float *pl = reinterpret_cast<float *>(smem);
     long long *sacc = reinterpret_cast<long long *>(smem + Cfg::SP_P_B);
     static_assert((Cfg::SMEM_B - Cfg::SP_P_B) / 8 >= Cfg::UW * CH + 64, "accumulators of all the group's channels + dummies");
-    const int c_lo = u0 * CH;                                  // the group's channels: [c_lo, c_lo + cn)
-    const int cn = n_units_valid * CH;
-    const int HWv = (n_units_valid + Cfg::UPH - 1) / Cfg::UPH; // its heads: [h0, h0 + HWv)
+    constexpr int NACC = (Cfg::SMEM_B - Cfg::SP_P_B) / 8 - 64;      // accumulators in front of the 64 dummies
     constexpr int RB = KVQ_V_RB;    // entries per lane and block, all loads in flight together
     constexpr int PE = 16;          // staged probabilities per lane and batch
-    const int G = a.groups;
-    const bool edge_group = G > 1 && (g == 0 || g == G - 1);
-    const int j0 = edge_group ? (a.n_out < KVQ_V_WIN ? a.n_out : KVQ_V_WIN) : a.n_out;   // slots of the first window
 #if KVQ_TRACE
     auto sstamp = [&](int k) {
       unsigned long long tt;
@@ -371,123 +373,116 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       tr_prev = (unsigned)tt;
     };
 #endif
-    for (int pass = 0; pass < 2; pass++) {
-      // window of this pass: slots [w_lo, w_lo + w_n) of every row
-      const int w_n = pass == 0 ? j0 : a.n_out - j0;
-      if (w_n <= 0) break;
-#if KVQ_TRACE
-      tr_passes++;
-#endif
-      const int w_lo = (g == 0 || !edge_group) ? (pass == 0 ? 0 : j0) : (pass == 0 ? a.n_out - j0 : 0);
-      // the slot next to the rest of the row: when an entry there still belongs to this group, the rest may too
-      const int edge_s = (g == 0 || !edge_group) ? w_n - 1 : 0;
-      const uint32_t w_magic = (uint32_t)(((1ull << 32) + (uint64_t)w_n - 1) / (uint64_t)w_n);
-      // token blocks: the entries of a block fit one round, its probabilities the stage
-      int sb = (RB * Cfg::NT) / w_n;
-      if (sb > Cfg::NT) sb = Cfg::NT;
-      if (sb > Cfg::SP_P_B / (4 * HWv) - 1) sb = Cfg::SP_P_B / (4 * HWv) - 1;
-      if (sb < 1) return;
-      int more = 0;
-      for (int64_t b0 = t0; b0 < t1; b0 += sb) {
-        const int ns = (t1 - b0 < sb) ? (int)(t1 - b0) : sb;     // tokens of the block
-        const unsigned nent = (unsigned)ns * (unsigned)w_n;      // <= RB * NT
-        // buffer descriptors over the block's entries and the group's score rows: every load below is a wave-uniform
-        // descriptor + ONE 32-bit lane offset (no 64-bit address pairs: 48 loads in flight per lane)
-        const __amdgpu_buffer_rsrc_t r_idx = uniform_rsrc(a.idx + b0 * a.n_out, nent_row(ns, a.n_out) * 4u);
-        const __amdgpu_buffer_rsrc_t r_val = uniform_rsrc(
-            compact ? reinterpret_cast<const float *>(a.idx + b0 * a.n_out) : a.outliers + b0 * a.n_out, nent_row(ns, a.n_out) * 4u);
-        const __amdgpu_buffer_rsrc_t r_p = uniform_rsrc((FUSED ? a.scores : a.p) + (int64_t)h0 * a.L + b0, 0x7ffffffcu);   // FUSED: raw scores, converted on the way
-        int row[RB];
-        float val[RB];
-        // (an opaque copy of the thread id per block: otherwise hipcc hoists the entry -> token divisions out of the
-        //  block loop and spills them)
-        unsigned tid_b = tid;
-        asm volatile("" : "+v"(tid_b));
+    const int w_n = a.n_out;
+    const uint32_t w_magic = a.n_out_magic;
+    // token blocks: the entries of a block fit one round, its probabilities the stage
+    int sb = w_n > 0 ? (RB * Cfg::NT) / w_n : 0;
+    if (sb > Cfg::NT) sb = Cfg::NT;
+    if (sb > Cfg::SP_P_B / (4 * HWv) - 1) sb = Cfg::SP_P_B / (4 * HWv) - 1;
+    if (sb < 1) return;
+    for (int64_t b0 = ts0; b0 < ts1; b0 += sb) {
+      const int ns = (ts1 - b0 < sb) ? (int)(ts1 - b0) : sb;     // tokens of the block
+      const unsigned nent = (unsigned)ns * (unsigned)w_n;        // <= RB * NT
+      // buffer descriptors over the block's entries and the score rows: every load below is a wave-uniform descriptor +
+      // ONE 32-bit lane offset (no 64-bit address pairs: 40 loads in flight per lane)
+      const __amdgpu_buffer_rsrc_t r_idx = uniform_rsrc(a.idx + b0 * a.n_out, nent_row(ns, a.n_out) * 4u);
+      const __amdgpu_buffer_rsrc_t r_val = uniform_rsrc(
+          compact ? reinterpret_cast<const float *>(a.idx + b0 * a.n_out) : a.outliers + b0 * a.n_out, nent_row(ns, a.n_out) * 4u);
+      const __amdgpu_buffer_rsrc_t r_p = uniform_rsrc((FUSED ? a.scores : a.p) + (int64_t)hf0 * a.L + b0, 0x7ffffffcu);   // FUSED: raw scores, converted on the way
+      int row[RB];
+      float val[RB];
+      // (an opaque copy of the thread id per block: otherwise hipcc hoists the entry -> token divisions out of the
+      //  block loop and spills them)
+      unsigned tid_b = tid;
+      asm volatile("" : "+v"(tid_b));
 #pragma unroll
-        for (int j = 0; j < RB; j++) {
-          const unsigned e = j * Cfg::NT + tid_b;
-          const unsigned ec = e < nent ? e : nent - 1;
-          const unsigned tl = __umulhi(ec, w_magic);             // token within the block, slot within the window
-          const unsigned off = (ec + tl * (unsigned)(a.n_out - w_n) + (unsigned)w_lo) * 4u;
-          // (Compact rows: `r_val` aliases the packed array, the second load hits the line the first one fetched.)
-          const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_idx, off, 0, 0);
-          const float fv = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_val, off, 0, 0));
-          row[j] = compact ? (int)(w & 0xffffu) : (int)w;
-          val[j] = compact ? __half2float(__ushort_as_half((unsigned short)(w >> 16))) : fv;
-        }
-        const int nsp = ns | 1;                     // odd row stride: consecutive heads fall into different LDS banks
-        {
-          // the block's probabilities of the group's heads: lanes along the tokens (coalesced), PE loads per lane in flight
-          const float rns = 1.0f / (float)ns;
-          const unsigned nel = (unsigned)HWv * (unsigned)ns;
-          for (unsigned k0 = 0; k0 < nel; k0 += PE * Cfg::NT) {
-            float v[PE];
+      for (int j = 0; j < RB; j++) {
+        const unsigned e = j * Cfg::NT + tid_b;
+        const unsigned ec = e < nent ? e : nent - 1;
+        // (Compact rows: `r_val` aliases the packed array, the second load hits the line the first one fetched.)
+        const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_idx, ec * 4u, 0, 0);
+        const float fv = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_val, ec * 4u, 0, 0));
+        row[j] = compact ? (int)(w & 0xffffu) : (int)w;
+        val[j] = compact ? __half2float(__ushort_as_half((unsigned short)(w >> 16))) : fv;
+      }
+      const int nsp = ns | 1;                     // odd row stride: consecutive heads fall into different LDS banks
+      {
+        // the block's probabilities of the heads: lanes along the tokens (coalesced), PE loads per lane in flight
+        const float rns = 1.0f / (float)ns;
+        const unsigned nel = (unsigned)HWv * (unsigned)ns;
+        for (unsigned k0 = 0; k0 < nel; k0 += PE * Cfg::NT) {
+          float v[PE];
 #pragma unroll
-            for (int k = 0; k < PE; k++) {
-              const unsigned e = k0 + k * Cfg::NT + tid_b;
-              const unsigned ec = e < nel ? e : nel - 1;
-              const unsigned hh = (unsigned)(((float)ec + 0.5f) * rns);      // ec / ns (exact: the quotient is never within 0.5 / ns of an integer)
-              const unsigned tl = ec - hh * (unsigned)ns;
-              v[k] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_p, (hh * (unsigned)a.L + tl) * 4u, 0, 0));
-            }
+          for (int k = 0; k < PE; k++) {
+            const unsigned e = k0 + k * Cfg::NT + tid_b;
+            const unsigned ec = e < nel ? e : nel - 1;
+            const unsigned hh = (unsigned)(((float)ec + 0.5f) * rns);      // ec / ns (exact: the quotient is never within 0.5 / ns of an integer)
+            const unsigned tl = ec - hh * (unsigned)ns;
+            v[k] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_p, (hh * (unsigned)a.L + tl) * 4u, 0, 0));
+          }
 #pragma unroll
-            for (int k = 0; k < PE; k++) {
-              const unsigned e = k0 + k * Cfg::NT + tid_b;
-              const unsigned ec = e < nel ? e : nel - 1;
-              const unsigned hh = (unsigned)(((float)ec + 0.5f) * rns);
-              const unsigned tl = ec - hh * (unsigned)ns;
-              if (e < nel)
-                pl[hh * nsp + tl] = FUSED ? prob_of(v[k], a.inv, mz[h0 + hh].x, mz[h0 + hh].y) : v[k];
-            }
+          for (int k = 0; k < PE; k++) {
+            const unsigned e = k0 + k * Cfg::NT + tid_b;
+            const unsigned ec = e < nel ? e : nel - 1;
+            const unsigned hh = (unsigned)(((float)ec + 0.5f) * rns);
+            const unsigned tl = ec - hh * (unsigned)ns;
+            if (e < nel)
+              pl[hh * nsp + tl] = FUSED ? prob_of(v[k], a.inv, mz[hf0 + hh].x, mz[hf0 + hh].y) : v[k];
           }
         }
-#if KVQ_TRACE
-        sstamp(6);
-#endif
-        __syncthreads();                            // staged probabilities visible
-#if KVQ_TRACE
-        sstamp(7);
-#endif
-        // (a second opaque copy: the entry -> (token, slot) arithmetic is done again instead of being kept -- spilled --
-        //  across the loads)
-        unsigned tid_c = tid;
-        asm volatile("" : "+v"(tid_c));
-#pragma unroll
-        for (int j = 0; j < RB; j++) {
-          const unsigned e = j * Cfg::NT + tid_c;
-          const unsigned ec = e < nent ? e : nent - 1;
-          const unsigned tl = __umulhi(ec, w_magic);
-          const unsigned sl_e = ec - tl * (unsigned)w_n;           // slot within the window
-          const unsigned rel = (unsigned)(row[j] - c_lo);          // channel within the group
-          const bool mine = e < nent && rel < (unsigned)cn;
-          const unsigned hh = mine ? (rel >> 7) : 0u;
-          const float pt = pl[hh * nsp + tl];
-          more |= (mine && sl_e == (unsigned)edge_s) ? 1 : 0;
-          // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
-          const float x = mine ? val[j] * pt : 0.f;
-          const float fl = floorf(x);
-          const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
-          const int hi = (int)fl;
-          const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
-          // (another group's entry, or none: + 0 into this lane's dummy accumulator -- no branch)
-          const unsigned slot = mine ? rel : (unsigned)(Cfg::UW * CH) + (tid_c & 63u);
-          atomicAdd(reinterpret_cast<unsigned long long *>(&sacc[slot]), fx);
-        }
-#if KVQ_TRACE
-        sstamp(8);
-#endif
-        // the stage may be rewritten / the sums are complete; does any token have entries of this group beyond the window?
-        more = __syncthreads_or(more);
-#if KVQ_TRACE
-        sstamp(9);
-#endif
       }
-      if (!edge_group || !more) break;
+#if KVQ_TRACE
+      sstamp(6);
+#endif
+      __syncthreads();                            // staged probabilities visible
+#if KVQ_TRACE
+      sstamp(7);
+#endif
+      // (a second opaque copy: the entry -> (token, slot) arithmetic is done again instead of being kept -- spilled --
+      //  across the loads)
+      unsigned tid_c = tid;
+      asm volatile("" : "+v"(tid_c));
+#pragma unroll
+      for (int j = 0; j < RB; j++) {
+        const unsigned e = j * Cfg::NT + tid_c;
+        const unsigned ec = e < nent ? e : nent - 1;
+        const unsigned tl = __umulhi(ec, w_magic);               // token within the block
+        const unsigned rel = (unsigned)(row[j] - c_lo);          // channel within the span
+        const bool mine = e < nent && rel < (unsigned)cn;
+        const unsigned hh = mine ? (rel >> 7) : 0u;
+        const float pt = pl[hh * nsp + tl];
+        // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
+        const float x = mine ? val[j] * pt : 0.f;
+        const float fl = floorf(x);
+        const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
+        const int hi = (int)fl;
+        const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
+        // (a padding entry: + 0 into this lane's dummy accumulator -- no branch)
+        const unsigned slot = mine ? rel : (unsigned)NACC + (tid_c & 63u);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sacc[slot]), fx);
+      }
+#if KVQ_TRACE
+      sstamp(8);
+#endif
+      __syncthreads();                            // the stage may be rewritten / the sums are complete
+#if KVQ_TRACE
+      sstamp(9);
+#endif
     }
   };
+  // this workgroup's share of the range's tokens when the outlier entries are split by tokens (a.split)
+  const int64_t split_share = ((t1 - t0) + a.groups - 1) / a.groups;
+  const int64_t split_t0 = (t0 + g * split_share < t1) ? t0 + g * split_share : t1;
+  const int64_t split_t1 = (split_t0 + split_share < t1) ? split_t0 + split_share : t1;
   auto sparse_phase = [&]() {
-    if (a.groups == 1) sparse_phase_one();
-    else sparse_phase_rows();
+    if (a.groups == 1 || a.split) {
+      // (one call site: the arguments are wave-uniform selects)
+      const bool sp = a.split != 0;
+      sparse_phase_all(sp ? split_t0 : t0, sp ? split_t1 : t1, sp ? 0 : u0 * CH, sp ? C : n_units_valid * CH, sp ? 0 : h0,
+                       sp ? a.H : (n_units_valid + Cfg::UPH - 1) / Cfg::UPH);
+    } else {
+      sparse_phase_rows();
+    }
   };
   // the lane that stores a unit half's channels at the end (slot 0), its slice of the partial slab and of the accumulators
   // (computed from an opaque copy of the thread id wherever it is needed, so that none of it stays live across the dense
@@ -500,8 +495,29 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     Slice r;
     r.writer = sl_ == 0 && ul_ < n_units_valid;
     r.dst = a.partial + ((int64_t)range * a.q_len + b) * C + (int64_t)(u0 + ul_) * CH + hf_ * CHL;
-    r.sacc = reinterpret_cast<long long *>(smem + Cfg::SP_P_B) + ul_ * CH + hf_ * CHL;
+    r.sacc = reinterpret_cast<long long *>(smem + Cfg::SP_P_B) + (a.split ? u0 * CH : 0) + ul_ * CH + hf_ * CHL;   // (split: indexed by the layer's channel)
     return r;
+  };
+  // split by tokens: every accumulator of the layer is this workgroup's; after the phase the sums of the OTHER groups'
+  // channels go to the extra slabs (see sparse_phase_all)
+  auto zero_all_acc = [&]() {
+    long long *sa = reinterpret_cast<long long *>(smem + Cfg::SP_P_B);
+    for (int i = tid; i < C; i += Cfg::NT) sa[i] = 0;
+  };
+  auto write_foreign = [&]() {
+    const long long *sa = reinterpret_cast<const long long *>(smem + Cfg::SP_P_B);
+    const int G = a.groups, n_ranges = (int)gridDim.x / G;
+    constexpr int GC = Cfg::UW * CH;                                   // channels of a full unit group
+    for (int j = 0; j + 1 < G; j++) {
+      const int x = (g + 1 + j) % G;
+      const int gcx = (C - x * GC < GC) ? C - x * GC : GC;
+      float *slab = a.partial + (int64_t)(n_ranges + range * (G - 1) + j) * C + x * GC;
+      for (int c = tid * 4; c < gcx; c += Cfg::NT * 4) {
+        const long long *q4 = sa + x * GC + c;
+        *reinterpret_cast<float4 *>(slab + c) = make_float4((float)((double)q4[0] * (1.0 / 4294967296.0)), (float)((double)q4[1] * (1.0 / 4294967296.0)),
+                                                             (float)((double)q4[2] * (1.0 / 4294967296.0)), (float)((double)q4[3] * (1.0 / 4294967296.0)));
+      }
+    }
   };
   if (sparse_first) {
     const Slice sc = slice_of();
@@ -510,12 +526,15 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     long long *sacc_w = sc.sacc;
     // phase first: its sums wait in this workgroup's slab (global memory; the registers are needed by the loop) and are
     // picked up again by the same lanes at the end
-    if (writer) {
+    if (a.split) {
+      zero_all_acc();
+    } else if (writer) {
 #pragma unroll
       for (int i = 0; i < CHL; i++) sacc_w[i] = 0;
     }
     __syncthreads();
     sparse_phase();
+    if (a.split) write_foreign();
     if (writer) {
 #pragma unroll
       for (int i = 0; i < CHL; i += 4) {
@@ -796,11 +815,12 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
       for (int k = 1; k < Cfg::SLOTS; k++) s += red[(i * Cfg::SLOTS + k) * (Cfg::UW * Cfg::HALVES) + lu];
       o[i] = s;
     }
-    if (sparse && !sparse_first) {
+    if (sparse && !sparse_first && !a.split) {
 #pragma unroll
       for (int i = 0; i < CHL; i++) sacc_w[i] = 0;     // (the writers cover exactly the group's channels)
     }
   }
+  if (sparse && !sparse_first && a.split) zero_all_acc();
 #if KVQ_TRACE
   {
     unsigned long long tt;
@@ -835,6 +855,7 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
     }
     __syncthreads();   // the slot sums are read, the accumulators zeroed: the stage may be overwritten
     sparse_phase();    // (ends with a barrier: the sums are complete)
+    if (a.split) write_foreign();
     const Slice sc2 = slice_of();
     if (sc2.writer) {
       typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -971,7 +992,7 @@ __global__ __launch_bounds__(256) void softmax_merge_kernel(const float *__restr
 struct Plan {
   int64_t tr;
   int n_ranges, groups, n_units;
-  size_t bytes;
+  size_t bytes;          // (room for the extra slabs of the token-split outlier phase: n_ranges * groups slabs at q_len = 1)
 };
 
 template <int BITS>
@@ -988,12 +1009,20 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   pl.tr = tr;
   pl.n_ranges = (int)((L + tr - 1) / tr);
   if (pl.n_ranges < 1) pl.n_ranges = 1;
-  pl.bytes = (size_t)pl.n_ranges * q_len * H * kHeadDim * sizeof(float) +
+  pl.bytes = (size_t)pl.n_ranges * (q_len == 1 ? pl.groups : q_len) * H * kHeadDim * sizeof(float) +
              (size_t)H * 2 * sizeof(float);   // + the (max, normaliser) pairs of the fused softmax
   return pl;
 }
 
-constexpr int kMergeInKernelParts = KVQ_V_MERGE_PARTS;   // up to this many score tiles (256 tokens each): the p.V workgroups merge the softmax partials themselves
+constexpr int kMergeInKernelParts = KVQ_V_MERGE_PARTS;
+// KVQ_V_SPLIT=0: the per-group rows phase at every length (A/B runs)
+static bool split_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("KVQ_V_SPLIT");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}   // up to this many score tiles (256 tokens each): the p.V workgroups merge the softmax partials themselves
 
 template <int BITS>
 static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, const FusedSoftmax *fs = nullptr) {
@@ -1003,6 +1032,13 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   a.groups = pl.groups;
   a.n_units = pl.n_units;
   dim3 grid(pl.n_ranges * pl.groups, 1, a.q_len), block(Cfg::NT);
+  // Outlier entries split by tokens between the unit groups of a range (sparse_phase_all): long caches, where the phase is
+  // bound by the bytes every group re-reads (128K nuq4: see DESIGN.md); short ones keep the per-group rows (the groups
+  // merge the softmax partials of their own heads only, and the extra slabs would double the reduce's work)
+  const int C_all = a.H * kHeadDim;
+  a.split = (a.idx != nullptr && a.q_len == 1 && pl.groups >= 2 && C_all <= (Cfg::SMEM_B - Cfg::SP_P_B) / 8 - 64 &&
+             a.H <= Cfg::SP_P_B / (4 * 65) && (fs ? fs->n_parts > kMergeInKernelParts : a.L >= 65536) && split_enabled()) ? 1 : 0;
+  const int n_slabs = a.split ? pl.n_ranges * pl.groups : pl.n_ranges;
   if (fs) {
     a.scores = fs->scores;
     a.inv = fs->inv;
@@ -1016,7 +1052,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
     if (fs->v_sink != nullptr) accumulate = 1;     // the reduce adds the slabs onto the sink tokens' output
     a.mz = nullptr;
     if (fs->n_parts > kMergeInKernelParts) {
-      float *mz = a.partial + (size_t)pl.n_ranges * a.q_len * a.H * kHeadDim;   // (tail of the workspace)
+      float *mz = a.partial + (size_t)pl.n_ranges * (a.q_len == 1 ? pl.groups : a.q_len) * a.H * kHeadDim;   // (tail of the workspace)
       softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz,
                                                 fs->v_sink, mul);
       int rc0 = check_launch();
@@ -1032,7 +1068,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   if (rc) return rc;
   const int C = a.H * kHeadDim;
   dim3 rgrid((C + 15) / 16, a.q_len);
-  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, mul, pl.n_ranges, a.q_len, C, accumulate);
+  mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, mul, n_slabs, a.q_len, C, accumulate);
   return check_launch();
 }
 

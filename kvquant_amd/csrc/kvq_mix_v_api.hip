@@ -89,6 +89,7 @@ static int mix_v_any(int bits, const float *p, const FusedSoftmax *fs, const int
   a.groups = 1;
   a.n_units = 0;
   a.n_out = n_out;
+  a.split = 0;
   a.n_out_magic = sparse ? (uint32_t)(((1ull << 32) + (uint64_t)n_out - 1) / (uint64_t)n_out) : 0u;
   a.scores = nullptr;
   a.mz = nullptr;

@@ -73,6 +73,7 @@ struct MixArgs {
   int groups;              // unit groups (workgroups per range)
   int n_units;
   int n_out;
+  int split;               // outlier entries split by TOKENS between the unit groups of a range (kvq_mix_v.hip: sparse_phase_all)
   uint32_t n_out_magic;    // ceil(2^32 / n_out)
   // FUSED softmax (decode, q_len = 1): `p` is unused; the kernel reads the RAW scores and converts them to
   // probabilities on the way (exactly the arithmetic of kvq_softmax_finish: half(expf(half(half(s) * inv) - M) / Z))

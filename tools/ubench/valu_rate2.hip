@@ -37,6 +37,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define I_PKADD(n) "v_pk_add_f32 %" #n ", %8, %" #n "\n"
 #define I_PKFMA16(n) "v_pk_fma_f16 %" #n ", %8, %9, %" #n "\n"
 #define I_DOT2C(n) "v_dot2c_f32_f16 %" #n ", %8, %9\n"
+#define I_ANDLIT(n) "v_and_b32 %" #n ", 0x78787878, %8\n"
+#define I_ANDFF(n) "v_and_b32 %" #n ", 0xff, %8\n"
+#define I_MOVSDWA(n) "v_mov_b32_sdwa %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n"
+#define I_ORSDWA(n) "v_or_b32_sdwa %" #n ", %9, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"
+#define I_LSHLSDWA(n) "v_lshlrev_b32_sdwa %" #n ", %9, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I_LSHLI(n) "v_lshlrev_b32 %" #n ", 3, %8\n"
+#define I_CNDMASK(n) "v_cndmask_b32 %" #n ", %8, %9, vcc\n"
+#define I_FMACS(n) "v_fmac_f32 %" #n ", %10, %9\n"
+#define I_DOT2(n) "v_dot2_f32_f16 %" #n ", %8, %9, %" #n "\n"
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned sg) {
@@ -72,6 +81,13 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned sg) 
     if (MODE == 24) { REP8(P8(I_PKADD)) }
     if (MODE == 25) { REP8(F8(I_PKFMA16)) }
     if (MODE == 26) { REP8(F8(I_DOT2C)) }
+    if (MODE == 27) { REP8(U8(I_ANDLIT)) }
+    if (MODE == 28) { REP8(U8(I_ANDFF)) }
+    if (MODE == 29) { REP8(U8(I_MOVSDWA)) }
+    if (MODE == 30) { REP8(U8(I_ORSDWA)) }
+    if (MODE == 31) { REP8(U8(I_LSHLSDWA)) }
+    if (MODE == 32) { REP8(U8(I_LSHLI)) }
+    if (MODE == 33) { REP8(U8(I_CNDMASK)) }
   }
   float s = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + (p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7).x;
   unsigned us = u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7;
@@ -100,5 +116,6 @@ int main() {
   RUN(10, "v_bfe_u32 imm") RUN(11, "v_bfe_u32 vgpr") RUN(12, "v_and_or_b32") RUN(13, "v_lshl_or_b32") RUN(14, "v_cvt_f32_ubyte1")
   RUN(15, "v_mov_b32") RUN(16, "v_xor3_b32") RUN(17, "v_add3_u32") RUN(18, "v_fmac_f32") RUN(19, "v_fma_f32") RUN(20, "v_mul_f32")
   RUN(21, "v_add_f32") RUN(22, "v_sin_f32") RUN(23, "v_pk_fma_f32") RUN(24, "v_pk_add_f32") RUN(25, "v_pk_fma_f16") RUN(26, "v_dot2c_f32_f16")
+  RUN(27, "v_and_b32 literal") RUN(28, "v_and_b32 0xff") RUN(29, "v_mov_b32_sdwa byte") RUN(30, "v_or_b32_sdwa byte") RUN(31, "v_lshlrev_b32_sdwa byte") RUN(32, "v_lshlrev_b32 imm") RUN(33, "v_cndmask_b32 vcc")
   return 0;
 }
