@@ -92,28 +92,31 @@ __global__ __launch_bounds__(kAW * 64, kAW == 8 ? 2 : 2) void prefill_attn_kerne
   // ---- staging: thread -> (key = tid & 63, 16-byte chunks c = (tid >> 6) + kAW j, j < 16 / kAW) of K and V
   constexpr int NCH = 16 / kAW;
   const int skey = tid & 63, sc0 = tid >> 6;
-  uint4 kreg[NCH], vreg[NCH];
-  auto load_tile = [&](int t) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // (a native vector: HIP's uint4 class ends up on the stack here)
+  u32x4 kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
     int key = t * kKV + skey;
     if (key >= a.S) key = a.S - 1;
     const f16 *kp = kh + (int64_t)key * a.kss;
     const f16 *vp = vh + (int64_t)key * a.vss;
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-      kreg[j] = *reinterpret_cast<const uint4 *>(kp + (sc0 + kAW * j) * 8);
-      vreg[j] = *reinterpret_cast<const uint4 *>(vp + (sc0 + kAW * j) * 8);
+      kreg[j] = *reinterpret_cast<const u32x4 *>(kp + (sc0 + kAW * j) * 8);
+      vreg[j] = *reinterpret_cast<const u32x4 *>(vp + (sc0 + kAW * j) * 8);
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage) __attribute__((always_inline)) {
     unsigned char *ks = smem + stage * kStage;
     unsigned char *vs = ks + kKTile;
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       const int c = sc0 + kAW * j;                                      // 16-byte chunk (8 d values)
-      *reinterpret_cast<uint4 *>(ks + skey * kKRow + ((c ^ (skey & 15)) << 4)) = kreg[j];
-      const f16 *e = reinterpret_cast<const f16 *>(&vreg[j]);
+      *reinterpret_cast<u32x4 *>(ks + skey * kKRow + ((c ^ (skey & 15)) << 4)) = kreg[j];
+      // (the eight halves cut out of the four words: no pointer into the staging registers)
+      const uint32_t wv[4] = {vreg[j].x, vreg[j].y, vreg[j].z, vreg[j].w};
 #pragma unroll
-      for (int i = 0; i < 8; i++) *reinterpret_cast<f16 *>(vs + (c * 8 + i) * kVRow + skey * 2) = e[i];
+      for (int i = 0; i < 8; i++)
+        *reinterpret_cast<unsigned short *>(vs + (c * 8 + i) * kVRow + skey * 2) = (unsigned short)(wv[i >> 1] >> (16 * (i & 1)));
     }
   };
 

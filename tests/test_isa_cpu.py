@@ -40,3 +40,16 @@ def test_checker_flags_a_spilled_in_flight_register(tmp_path):
         "\tscratch_store_dword off, v3, off", "\ts_endpgm", ""]))
     n, problems = check_isa.check(str(good))
     assert n == 1 and not problems
+
+
+def test_no_scratch_in_default_path_kernels():
+    """every kernel of the built library: scratch memory (register spills / stack objects) only where tools/check_scratch.py
+    tolerates it by name -- the legacy row-layout instantiations -- and nowhere in a default decode / append / prefill path"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_scratch
+    from kvquant_amd import build as kb
+    kb.build()
+    n, problems, tolerated = check_scratch.check()
+    assert n > 50, n
+    assert not problems, problems
+    assert len(tolerated) <= 6, tolerated
