@@ -65,6 +65,8 @@ def parse():
                          "stream whose context is split along the token axis (strong scaling, one all-gather per layer); "
                          "heads = ONE stream, every rank holds H / N heads of every layer (strong scaling, one all-gather "
                          "of the heads' outputs per layer)")
+    ap.add_argument("--prefill", action="store_true",
+                    help="BASELINE config 4 only: fused prefill pack (K, V) of an 8192-token prompt + the causal MFMA attention")
     ap.add_argument("--sweep", action="store_true", help="every BASELINE configuration, one JSON line each (1 GPU)")
     ap.add_argument("--retrieval", action="store_true", help="plant a retrievable token and check it (config 5 proxy)")
     ap.add_argument("--time-every", type=int, default=11,
@@ -657,6 +659,77 @@ def run_head_sharded(args, rank, world, dev, dist):
     }
 
 
+def run_prefill_config(bits, S, dev, iters=10):
+    """BASELINE config 4 as a driver-visible line: the fused prefill pack of an S-token prompt (one layer's K and V:
+    selection, codebook rows, codes, outlier rows + mirror -- kvq_pack_{k,v}_fused, what QuantK / QuantV.parallel_pack
+    run) and the causal prompt attention on the matrix cores (kvq_prefill_attention).  Pack bytes: the fp32 prompt read
+    once + the packed words, rows and mirror written; attention: 4 H S^2 d / 2 flops against the 2.5 PFLOP/s dense fp16 peak."""
+    from kvquant_amd import ops
+    from kvquant_amd.cache import QuantK, QuantV
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    quant, scale, shift = synth_quantizer(bits, gen, dev)
+    max_len = S + 64
+    kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+              sparsity_threshold=0.99, first_few_fp16=0, device=dev)
+    kc, vc = QuantK(rope_theta=THETA, **kw), QuantV(**kw)
+    for c in (kc, vc):
+        c.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+    k, v = synth_tokens(S, scale, shift, gen, dev)
+    k = k.float().t().reshape(H, HD, S).contiguous()
+    v = v.float().t().reshape(H, HD, S).contiguous()
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for it in range(iters + 2):
+            kc.klen = 0                    # (the pack writes columns 0 .. S-1 of an empty cache, ML:971-972)
+            vc.vlen = 0
+            kc.kcache.zero_()
+            vc.vcache.zero_()
+            if it < 2:                     # warm-up
+                fn()
+                continue
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / iters
+
+    k_ms = timed(lambda: kc.parallel_pack(k))
+    v_ms = timed(lambda: vc.parallel_pack(v))
+    k_bytes = C * S * 4 + C * S * bits // 8 + S * 42 * 8 * 2            # prompt + codes + rows + mirror
+    v_bytes = C * S * 4 + C * S * bits // 8 + S * 42 * 8 + S * (2 ** bits) * 4
+    x = [torch.randn(S, H, HD, device=dev, dtype=torch.float16, generator=gen) for _ in range(3)]
+    qa, ka, va = (t.transpose(0, 1) for t in x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        ops.prefill_attention(qa, ka, va)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.prefill_attention(qa, ka, va)
+    e1.record()
+    torch.cuda.synchronize()
+    a_ms = e0.elapsed_time(e1) / iters
+    flops = 4.0 * H * S * S * HD / 2
+    return {
+        "metric": "prefill: NUQ pack of an %d-token prompt (one layer, K and V) + causal MFMA attention, LLaMA-2-7B head shape, nuq%d 1%%-sparse"
+                  % (S, bits),
+        "value": S / ((k_ms + v_ms) * 1e-3), "unit": "tokens/s (pack K + V, one layer)", "n_gpus": 1, "steps": iters, "warmup": 2,
+        "ms_per_step": k_ms + v_ms, "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: prompt of %d tokens, H=32 hd=128, nuq%d + 1%% outliers (capped, 42/token)" % (S, bits),
+                   "label": "prefill S=%d nuq%d (config 4)" % (S, bits), "bits": bits, "S": S},
+        "roofline": {"bound": "hbm", "kernel": "pack_tiled_kernel (K)", "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": k_bytes / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": k_bytes, "avg_launch_us": k_ms * 1e3},
+        "kernels": {"pack_k_us": k_ms * 1e3, "pack_v_us": v_ms * 1e3, "pack_k_GBps": k_bytes / (k_ms * 1e-3) / 1e9,
+                    "pack_v_GBps": v_bytes / (v_ms * 1e-3) / 1e9, "prefill_attention_us": a_ms * 1e3,
+                    "prefill_attention_TFLOPs": flops / (a_ms * 1e-3) / 1e12,
+                    "prefill_attention_frac_of_2500_TF_dense_fp16": flops / (a_ms * 1e-3) / 1e12 / 2500.0},
+    }
+
+
 def cache_bytes_per_layer(bits, max_len, compact=False):
     """HBM bytes one layer's compressed K + V cache occupies for max_len token slots (kvquant_amd.cache.QuantK / QuantV):
     packed codes, outlier rows (+ the token-contiguous K mirror), the per-token V codebook rows"""
@@ -674,7 +747,22 @@ def check_memory(args, n_layers, streams, max_len, dev, what):
     need += 2 * H * max_len * 4 + (64 << 20)                      # scores + probabilities scratch, slabs, tables
     need += 3 * 8192 * C * 4                                      # the fill's prompt chunk in flight (K, V fp32 views)
     total = torch.cuda.get_device_properties(dev).total_memory
-    if need > 0.94 * total:
+    over = need > 0.94 * total
+    # (every rank decides together: a rank that exits alone leaves the others in their first collective until the
+    #  backend's timeout -- ADVICE r4)
+    dist_mod = None
+    try:
+        import torch.distributed as dist_mod
+        if not (dist_mod.is_available() and dist_mod.is_initialized() and dist_mod.get_world_size() > 1):
+            dist_mod = None
+    except Exception:
+        dist_mod = None
+    if dist_mod is not None:
+        flag = torch.tensor([1 if over else 0], device=dev if dist_mod.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+        dist_mod.all_reduce(flag, op=dist_mod.ReduceOp.MAX)
+        if int(flag.item()) and not over:
+            raise SystemExit("bench.py: another rank does not have the HBM for its share (%s fits here): stopping together" % what)
+    if over:
         raise SystemExit("bench.py: %s needs %.1f GB of HBM on this GPU (%d layers x %d stream(s) x %d token slots x %d B "
                          "per token and layer + scratch) but the device has %.1f GB: use more GPUs (--gpus), fewer streams "
                          "(--streams) or a shorter context (--ctx)"
@@ -763,9 +851,10 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
         k_us, v_us = timers.mean_us("score_k"), timers.mean_us("mix_v")
         kb, _ = algorithmic_bytes(args.bits, L_mid, "score_k", getattr(args, "compact", False))
         vb, _ = algorithmic_bytes(args.bits, L_mid, "mix_v", getattr(args, "compact", False))
-        from kvquant_amd import cache as kcache_mod
-        fused_attend = kcache_mod.FUSED_ATTEND if kcache_mod.FUSED_ATTEND is not None else \
-            (args.bits == 4 and L_mid >= kcache_mod.FUSED_ATTEND_FROM)
+        # (the route the library actually took on the last step -- not a guess from the thresholds: a request for the fused
+        #  kernel falls back to the kernel pair for compact caches, Q-Norm tables, unsupported shapes)
+        from kvquant_amd import _lib as _klib
+        fused_attend = _klib.lib().kvq_decode_step_route() == 3
         if fused_attend:
             # one kernel per layer (kvq_fused_attend: the library's event pairs are then the fused kernel and its merge);
             # its algorithmic bytes: both matvecs' minus the score write / probability read that no longer exist
@@ -826,6 +915,13 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
                          "timed_launches": len(timers.quads) or len(timers.pairs[dom]),
                          "timing": "HIP events on the launch stream around every %d-th layer's launch inside the timed region"
                                    % max(args.time_every, 1)},
+            # the whole step against the same peak: every layer's algorithmic bytes (both matvecs) / the step's wall time
+            "roofline_step": {"bound": "hbm", "achieved": len(owned) * streams * (kb + vb) / (elapsed / args.steps) / 1e9,
+                              "peak": 8000.0, "unit": "GB/s",
+                              "frac": len(owned) * streams * (kb + vb) / (elapsed / args.steps) / 1e9 / 8000.0,
+                              "algorithmic_bytes_per_step": len(owned) * streams * (kb + vb),
+                              "what": "q.K^T + p.V bytes of every layer / ms_per_step (appends, softmax merge, slab reduce "
+                                      "and launch gaps are in the time, not in the bytes)"},
             "kernels": ({"fused_attend_us": k_us, "fused_merge_us": v_us,
                          "kv_matvec_GBps": dom_bytes / ((k_us + v_us) * 1e-6) / 1e9 if k_us and v_us else None,
                          "step_GBps": len(owned) * streams * dom_bytes / (elapsed / args.steps) / 1e9} if fused_attend else
@@ -928,6 +1024,12 @@ def main():
             a.retrieval = ctx >= 1048576 and not compact
             r = run_config(a, rank, world, dev, dist, label=label, with_baselines=False)
             print(json.dumps(r), flush=True)
+        for bits in (4, 3):
+            print(json.dumps(run_prefill_config(bits, 8192, dev)), flush=True)
+    if getattr(args, "prefill", False):
+        if rank == 0:
+            print(json.dumps(run_prefill_config(args.bits, 8192, dev)), flush=True)
+        return
     if args.shard != "layers" and (args.sinks or getattr(args, "compact", False) or args.retrieval):
         raise SystemExit("bench.py --shard %s: fp16 sink tokens, the compact outlier format and the retrieval check belong to the "
                          "layer placement (cache.shard_attention / HeadShard carry the reference format without sinks)" % args.shard)

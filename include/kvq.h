@@ -60,7 +60,7 @@ extern "C" {
  *        (b) the constant-table p.V kernel left the library (kvq_mix_v_softmax_affine, kvq_mix_v_affine_*: measured slower
  *        than the per-row kernel everywhere, tools/experiments/kvq_mix_va.hip keeps the source); kvq_decode_step
  *        fuse_softmax 1 and 2 are the same route now;  (c) kvq_score_k_workspace_bytes is larger at 3 bit (the fp16
- *        pair-sum tables live behind the fp32 ones);  (d) new entries: kvq_score_k_prepared_softmax_ex.
+ *        pair-sum tables live behind the fp32 ones);  (d) new entries: kvq_score_k_prepared_softmax_ex, kvq_decode_step_route.
  *        A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
 #define KVQ_ABI_MAJOR 4
 KVQ_API int kvq_version(void);
@@ -420,6 +420,10 @@ KVQ_API int kvq_decode_step(const kvq_layer *layer, int64_t kcol, int64_t vcol, 
  * behind the small merge of the softmax partials that long caches need) of the NEXT
  * kvq_decode_step on this thread; the hook clears itself after that call.  NULL: no events. */
 KVQ_API int kvq_decode_step_events(void *const *events4);
+/* the launch sequence the last kvq_decode_step on this thread took: 0 = softmax as its own launch, 1 = softmax inside the
+ * p.V kernel, 3 = kvq_fused_attend (a request for 3 that the shape does not allow runs as 1); -1 = none yet.  For callers
+ * that account bytes per kernel (bench.py). */
+KVQ_API int kvq_decode_step_route(void);
 /* the same for a stack of layers that follow each other without other work in between (all at the same column;
  * q / k / v / out: arrays of n_layers pointers; one workspace, reused layer after layer) */
 KVQ_API int kvq_decode_steps(int n_layers, const kvq_layer *layers, int64_t col, const void *const *q,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "kvq_decode_step_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
     "kvq_decode_step": (_i, [_ly, _i64, _i64, _vp, _vp, _vp, _i, _sk, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "kvq_decode_step_events": (_i, [_vp]),
+    "kvq_decode_step_route": (_i, []),
     "kvq_decode_steps": (_i, [_i, _ly, _i64, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "kvq_score_k_tables": (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_softmax_stats": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -48,15 +48,27 @@ class RotaryDynamic(nn.Module):
     def forward(self, x, start_pos, end_pos):
         inv = self.inv_freq
         key = (self.dim, self.base, inv.dtype, inv.device, x.dtype)
-        hit = RotaryDynamic._last.get(key)
-        if hit is not None and hit[0] == (start_pos, end_pos):
-            return hit[1], hit[2]
+        # (only decode-size requests are kept -- a prefill's [S, dim] tables would be pinned until the next call, 512 MB
+        #  after a 1M-token prompt -- and per CUDA stream: the cached tensors were produced on that stream)
+        small = end_pos - start_pos <= RotaryDynamic.CACHE_MAX_POSITIONS
+        if small:
+            key = key + (torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0,)
+            hit = RotaryDynamic._last.get(key)
+            if hit is not None and hit[0] == (start_pos, end_pos):
+                return hit[1], hit[2]
         t = torch.arange(start_pos, end_pos, device=x.device, dtype=torch.int64).type_as(inv)
         freqs = torch.outer(t, inv)
         emb = torch.cat((freqs, freqs), dim=-1)
         cos, sin = emb.cos().to(x.dtype), emb.sin().to(x.dtype)
-        RotaryDynamic._last[key] = ((start_pos, end_pos), cos, sin)
+        if small:
+            RotaryDynamic._last[key] = ((start_pos, end_pos), cos, sin)
         return cos, sin
+
+    CACHE_MAX_POSITIONS = 16
+
+    @classmethod
+    def clear_cache(cls):
+        cls._last.clear()
 
 
 class KVQuantAttention(nn.Module):

@@ -20,18 +20,14 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-MATVEC_SOURCES = ("kvq_score_k.hip", "kvq_score_k_tile.h", "kvq_ktab.h", "kvq_mix_v.hip", "kvq_mix_v_stage.h",
-                  "kvq_mix_lut.h", "kvq_common.h")
-
-
 def kernel_source_hash():
-    """sha256 over the CODE of the two matvec kernels' sources (// comments and white space stripped): stamps measured
-    per-kernel numbers that are kept in the tree (profiles/pmc_traffic.json), so that bench.py can tell when the kernels
-    have changed since they were measured"""
+    """sha256 over the CODE of every kernel source of the library (// comments and white space stripped) -- every launch
+    of the timed decode step comes from one of them: stamps measured per-kernel numbers that are kept in the tree
+    (profiles/pmc_traffic.json), so that bench.py can tell when the kernels have changed since they were measured"""
     import hashlib
     import re
     h = hashlib.sha256()
-    for f in MATVEC_SOURCES:
+    for f in sorted(x for x in os.listdir(CSRC) if x.endswith((".hip", ".h"))):
         with open(os.path.join(CSRC, f)) as fh:
             for line in fh:
                 line = re.sub(r"\s+", "", re.sub(r"//.*", "", line))

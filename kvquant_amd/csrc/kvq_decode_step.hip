@@ -47,6 +47,7 @@ static StepPlan plan_step(int bits, int H, int hd, int64_t L) {
 static thread_local hipEvent_t *step_events = nullptr;
 
 static thread_local bool mark2_pending = false;
+static thread_local int last_route = -1;      // which launch sequence the last kvq_decode_step on this thread took
 static thread_local int step_fused_mark = 0;
 static void record(int i, hipStream_t st) {
   if (step_events && step_events[i]) (void)hipEventRecord(step_events[i], st);
@@ -73,6 +74,8 @@ void kvq_step_mark_fused(hipStream_t st) {
     record(2, st);
   }
 }
+
+int kvq_decode_step_route(void) { return last_route; }
 
 int kvq_decode_step_events(void *const *events4) {
   step_events = reinterpret_cast<hipEvent_t *>(const_cast<void **>(events4));
@@ -116,6 +119,7 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
   if (fuse_softmax == 3 && ly->koutliers_t && ly->voutliers && !ly->v_mix_rows && !ly->klut_score &&
       kvq_fused_attend_supported(bits, H, hd, L, ly->max_len, n_out)) {
     // one kernel for q.K^T + softmax + p.V of every 256-token tile, then the merge (events: 0-1 the kernel, 2-3 the merge)
+    last_route = 3;
     record(0, st);
     step_fused_mark = 1;
     rc = kvq_fused_attend(bits, ly->kmat, ktab, ws, ly->vmat, ly->vlut_rows, H, hd, L, ly->max_len, ly->rope_theta,
@@ -126,6 +130,7 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
     record(3, st);
     return rc;
   }
+  last_route = fuse_softmax ? 1 : 0;
   record(0, st);
   rc = kvq_score_k_prepared_softmax_ex(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta,
                                        ly->pos_offset, ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws,

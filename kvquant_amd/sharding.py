@@ -213,6 +213,9 @@ def head_sharded_step(attend_fn, num_heads, head_dim, group=None, out=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     mine = attend_fn()
     if world == 1:
+        if out is not None:          # (a caller that reads its own buffer: same contract as with more ranks)
+            out.copy_(mine.reshape(out.shape))
+            return out
         return mine
     split = head_assignment(num_heads, world)
     widest = max(n for _, n in split)
