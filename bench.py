@@ -592,9 +592,17 @@ def run_head_sharded(args, rank, world, dev, dist):
     gen = torch.Generator(device=dev).manual_seed(1234)          # the same quantizers / tokens / queries on every rank
     t_setup = time.time()
     layers = []
+    # (priced at full width: a shard's outlier rows and codebook rows keep the token's width, only the packed words shrink)
+    check_memory(args, args.layers, 1, max_len, dev,
+                 "rank %d of %d (heads %d..%d of every layer, ctx %d, priced at full width)" % (rank, world, h0, h0 + n - 1, args.ctx))
+    stage = None          # ONE set of staging buffers for all layers of the rank (the tables stay per layer)
+    sinks = args.sinks
     for li in range(args.layers):
         quant, scale, shift = synth_quantizer(args.bits, gen, dev)
-        hs = HeadShard(args.bits, C, H, (h0, n), max_len, rope_theta=THETA, device=dev, stage_len=8192)
+        hs = HeadShard(args.bits, C, H, (h0, n), max_len, rope_theta=THETA, device=dev, stage_len=8192,
+                       first_few_fp16=sinks, staging=stage)
+        if stage is None:
+            stage = hs
         hs.load_lookup_table(quant, quant)
         fill = torch.Generator(device=dev).manual_seed(77 + li)
         done = 0
@@ -604,17 +612,22 @@ def run_head_sharded(args, rank, world, dev, dist):
             hs.pack(k.view(S, H, HD).permute(1, 2, 0).float(), v.view(S, H, HD).permute(1, 2, 0).float())
             done += S
         k, v = synth_tokens(total, scale, shift, gen, dev)
-        q = torch.randn(total, H, HD, generator=gen, device=dev).half()
-        layers.append((hs, q, k, v))
+        # (fp32 activations here: the dependency of a layer's query on the previous layer's gathered output is then ONE
+        #  torch launch per layer -- the library takes fp16 or fp32 alike)
+        k, v = k.float(), v.float()
+        q = torch.randn(total, H, HD, generator=gen, device=dev)
+        ks = (torch.randn(H, HD, sinks, generator=gen, device=dev) * 0.5).half()[h0:h0 + n].contiguous() if sinks else None
+        vs = torch.randn(H, sinks, HD, generator=gen, device=dev).half()[h0:h0 + n].contiguous() if sinks else None
+        layers.append((hs, q, k, v, ks, vs))
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
     gathered = torch.empty((1, H, HD), dtype=torch.float32, device=dev)
 
     def step(st):
         out = None
-        for hs, q, k, v in layers:
-            qq = q[st] if out is None else q[st] + out.view(H, HD).half() * 1e-3      # (a true dependency on the gather)
-            out = sharding.head_sharded_step(lambda: hs.attend(qq, k[st], v[st]), H, HD, out=gathered)
+        for hs, q, k, v, ks, vs in layers:
+            qq = q[st] if out is None else torch.add(q[st], out.view(H, HD), alpha=1e-3)   # (a true dependency on the gather)
+            out = sharding.head_sharded_step(lambda: hs.attend(qq, k[st], v[st], k_sink=ks, v_sink=vs), H, HD, out=gathered)
         return out
 
     for st in range(args.warmup):
@@ -1030,9 +1043,10 @@ def main():
         if rank == 0:
             print(json.dumps(run_prefill_config(args.bits, 8192, dev)), flush=True)
         return
-    if args.shard != "layers" and (args.sinks or getattr(args, "compact", False) or args.retrieval):
-        raise SystemExit("bench.py --shard %s: fp16 sink tokens, the compact outlier format and the retrieval check belong to the "
-                         "layer placement (cache.shard_attention / HeadShard carry the reference format without sinks)" % args.shard)
+    if args.shard != "layers" and (getattr(args, "compact", False) or args.retrieval or (args.sinks and args.shard == "tokens")):
+        raise SystemExit("bench.py --shard %s: the compact outlier format and the retrieval check belong to the layer placement; "
+                         "fp16 sink tokens are carried by --shard heads (cache.shard_attention takes them per call, "
+                         "run_token_sharded does not wire them)" % args.shard)
     if args.shard == "tokens":
         res = run_token_sharded(args, rank, world, dev, dist)
     elif args.shard == "heads":

@@ -60,7 +60,9 @@ extern "C" {
  *        (b) the constant-table p.V kernel left the library (kvq_mix_v_softmax_affine, kvq_mix_v_affine_*: measured slower
  *        than the per-row kernel everywhere, tools/experiments/kvq_mix_va.hip keeps the source); kvq_decode_step
  *        fuse_softmax 1 and 2 are the same route now;  (c) kvq_score_k_workspace_bytes is larger at 3 bit (the fp16
- *        pair-sum tables live behind the fp32 ones);  (d) new entries: kvq_score_k_prepared_softmax_ex, kvq_decode_step_route.
+ *        pair-sum tables live behind the fp32 ones);  (d) kvq_score_k_tables takes the shard's fp16 sink tokens, kvq_softmax_stats their
+ *        scores, kvq_extract_heads the Q-Norm rows;  (e) new entries: kvq_score_k_prepared_softmax_ex, kvq_decode_step_route,
+ *        kvq_append_kv_fused, kvq_attend_step, kvq_head_shard_step.
  *        A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
 #define KVQ_ABI_MAJOR 4
 KVQ_API int kvq_version(void);
@@ -434,12 +436,15 @@ KVQ_API int kvq_decode_steps(int n_layers, const kvq_layer *layers, int64_t col,
 
 /* The query-premultiplied K codebook images of kvq_score_k_prepared[_softmax] into `workspace`
  * (kvq_score_k_workspace_bytes(bits, 1, H)) without an append: the shards that do not hold the newest token only score.
- * q: [H][128] RoPE'd query, fp32 or fp16; lut: the table the scores dequantise with. */
+ * q: [H][128] RoPE'd query, fp32 or fp16; lut: the table the scores dequantise with.  sinks (optional): the fp16 sink
+ * tokens this shard holds -- their scaled scores are written as kvq_decode_prologue writes them. */
 KVQ_API int kvq_score_k_tables(int bits, const void *q, int q_is_half, const float *lut, int H, int hd,
-                       void *workspace, size_t workspace_bytes, void *stream);
+                       const kvq_sinks *sinks, void *workspace, size_t workspace_bytes, void *stream);
 /* stats[h] = (max, sum of exp(x - max)) of head h's scaled scores over the shard, merged from the partials that
- * kvq_score_k_prepared_softmax wrote (the per-row part of kvq_softmax_finish); float [H][2]. */
-KVQ_API int kvq_softmax_stats(const float *parts, int n_parts, int H, float *stats, void *stream);
+ * kvq_score_k_prepared_softmax wrote (the per-row part of kvq_softmax_finish) and, for the shard that holds them, the
+ * scaled scores of the fp16 sink tokens (fp16 [H][n_sink] or NULL / 0); float [H][2]. */
+KVQ_API int kvq_softmax_stats(const float *parts, int n_parts, const uint16_t *sink_scores, int n_sink, int H,
+                      float *stats, void *stream);
 /* Exact merge of n_shards locally normalised attention outputs (flash-decoding across devices): packed = n_shards
  * records of [H*hd floats: the shard's output][H x (max, normaliser): kvq_softmax_stats], e.g. the result of ONE
  * all-gather per layer; a shard without tokens carries (-inf, 0).  out: float [H][hd]. */
@@ -459,7 +464,29 @@ KVQ_API int kvq_extract_heads(int bits, int H, int hd, int h0, int n_heads, int 
                       const int32_t *k_idx_src, const float *v_out_src, const int32_t *v_idx_src,
                       const float *v_rows_src, int32_t *k_dst, int32_t *v_dst, int64_t dst_max_len, int64_t dst_col,
                       float *k_out_dst, int32_t *k_idx_dst, float *k_out_t_dst, int32_t *k_idx_t_dst, float *v_out_dst,
-                      int32_t *v_idx_dst, float *v_rows_dst, int64_t n, void *stream);
+                      int32_t *v_idx_dst, float *v_rows_dst, const float *v_rows2_src, float *v_rows2_dst, int64_t n,
+                      void *stream);
+/* K append | V append of one token into column `col` of a layer's cache as ONE launch (the two selection workgroups of
+ * kvq_decode_prologue without its table roles; k, v: [H*hd] fp32 or fp16). */
+KVQ_API int kvq_append_kv_fused(const kvq_layer *layer, int64_t col, const void *k, const void *v, int acts_are_half,
+                        void *stream);
+/* One decode token's attention over the L tokens a layer's cache already holds, WITHOUT an append: query tables (+ fp16
+ * sink scores) -> q.K^T -> softmax -> p.V (+ slab reduce): the launches of kvq_decode_step behind its prologue.  For the
+ * shards of a split stream.  Arguments as kvq_decode_step; workspace: kvq_decode_step_workspace_bytes(bits, H, hd, L). */
+KVQ_API int kvq_attend_step(const kvq_layer *layer, int64_t L, const void *q, int acts_are_half, const kvq_sinks *sinks,
+                    const uint16_t *v_sink, uint16_t *sink_probs, float *out, int fuse_softmax, void *workspace,
+                    size_t workspace_bytes, void *stream);
+/* One decode token through one HEAD SHARD of a layer, ONE call: kvq_append_kv_fused into column 0 of the full-width
+ * staging cache `full` (the selection is a property of the whole token: bit-identical on every rank), kvq_extract_heads
+ * of heads [h0, h0 + shard->H) into column `col` of the shard's cache (Q-Norm rows travel when both layers carry them),
+ * kvq_attend_step over the shard's col + 1 tokens.  q: the shard's heads of the RoPE'd query [shard->H][128]; k, v: the
+ * whole token; sinks / v_sink / sink_probs: the shard's heads of the fp16 sink caches; out f32 [shard->H][hd].
+ * workspace: kvq_decode_step_workspace_bytes(bits, shard->H, hd, col + 1).  `v_rows2_*` of kvq_extract_heads above: the
+ * Q-Norm codebook rows (kvq_vopts.lut_rows2) of the extracted tokens, or NULL. */
+KVQ_API int kvq_head_shard_step(const kvq_layer *full, const kvq_layer *shard, int h0, int64_t col, const void *q,
+                        const void *k, const void *v, int acts_are_half, const kvq_sinks *sinks, const uint16_t *v_sink,
+                        uint16_t *sink_probs, float *out, int fuse_softmax, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* ---- prefill attention (the MFMA path of BASELINE config 4) ----------------------- */
 

@@ -88,12 +88,15 @@ SIGNATURES = {
     "kvq_decode_step_events": (_i, [_vp]),
     "kvq_decode_step_route": (_i, []),
     "kvq_decode_steps": (_i, [_i, _ly, _i64, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
-    "kvq_score_k_tables": (_i, [_i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
-    "kvq_softmax_stats": (_i, [_vp, _i, _i, _vp, _vp]),
+    "kvq_score_k_tables": (_i, [_i, _vp, _i, _vp, _i, _i, _sk, _vp, _sz, _vp]),
+    "kvq_softmax_stats": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "kvq_combine_shards": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "kvq_rope_q_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "kvq_extract_heads": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "kvq_append_kv_fused": (_i, [_ly, _i64, _vp, _vp, _i, _vp]),
+    "kvq_attend_step": (_i, [_ly, _i64, _vp, _i, _sk, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "kvq_head_shard_step": (_i, [_ly, _ly, _i, _i64, _vp, _vp, _vp, _i, _sk, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "kvq_prefill_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "kvq_append_k_sparse_orig": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
     "kvq_append_v_sparse_orig": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),

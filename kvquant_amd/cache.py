@@ -649,26 +649,32 @@ def shard_record_floats(H, hd):
     return H * hd + 2 * H
 
 
-def shard_attention(kc, vc, q, k=None, v=None, pos_base=0, record=None):
+def shard_attention(kc, vc, q, k=None, v=None, pos_base=0, record=None, k_sink=None, v_sink=None):
     """Attention of one decode token over ONE SHARD of a context that is split along the token axis (SURVEY 8e asks
     for layer / head placement; this is the third cut, the one that speeds up a single long stream: every GPU holds
     L / N cached tokens of every layer and streams only those).  kc / vc hold the shard's tokens, whose positions
     start at `pos_base`; k, v (the new token) are appended to THIS shard when given -- the owner of the newest tokens
     -- and the other shards only score.  Everything stays in library launches (no torch arithmetic): table prep or
     prologue -> q.K^T + softmax partials -> softmax finish -> softmax statistics -> p.V -> slab reduce.
+    k_sink (f16 [H, 128, n_sink], post-RoPE) / v_sink (f16 [H, n_sink, 128]): the fp16 attention-sink tokens
+    (first_few_fp16, ML:1464-1466), handed to the shard that holds the START of the context (and only to it): their
+    scores enter that shard's softmax and its (max, normaliser), their values its output -- the merge across shards is
+    unchanged.  pos_base of that shard = the number of sink tokens (the position of its first compressed token).
     Returns (out f32 [1, H, hd] normalised over the shard, M f32 [H], Z f32 [H]) -- views of `record` (f32
     [shard_record_floats], allocated when None), the buffer that goes into the all-gather: the shard's softmax maximum
     and normaliser of the scaled fp16 scores, so that the shards merge exactly (flash-decoding across devices; the
     probabilities are rounded to fp16 per shard instead of over the whole row, a last-bit effect).  An EMPTY shard
-    (no cached tokens, no new one) returns zeros with (M, Z) = (-inf, 0).  Sparse caches with the outlier mirror;
-    fp16 sink tokens are not supported here (they would belong to the first shard only)."""
+    (no cached tokens, no new one, no sinks) returns zeros with (M, Z) = (-inf, 0).  Sparse caches with the outlier mirror."""
     if not (kc.include_sparse and vc.include_sparse):
         raise ValueError("shard_attention needs include_sparse caches")
-    if kc.first_few_fp16 > 0:
-        raise ValueError("shard_attention: fp16 attention-sink tokens are not supported on a sharded context")
+    if (k_sink is None) != (v_sink is None):
+        raise ValueError("shard_attention: k_sink and v_sink come together")
     if getattr(kc, "compact", False) or getattr(vc, "compact", False):
         raise NotImplementedError("shard_attention reads the reference outlier format; compact caches go through decode_kv")
     bits, H, hd = kc.bits, kc.num_heads, vc.head_dim
+    nf = kc.first_few_fp16                     # (sink tokens counted in klen, as in the reference's attention)
+    if kc.klen < nf or kc.lookup_table is None:
+        raise ValueError("shard_attention: the cache counts %d sink tokens in klen = %d / has no tables loaded" % (nf, kc.klen))
     if record is None:
         record = torch.empty(shard_record_floats(H, hd), dtype=torch.float32, device=kc.device)
     out = record[:H * hd].view(1, H, hd)
@@ -676,25 +682,37 @@ def shard_attention(kc, vc, q, k=None, v=None, pos_base=0, record=None):
     inv = 1.0 / (kc.head_dim ** 0.5)
     table = kc.lookup_table2 if (kc.norm and bits == 2) else kc.lookup_table
     pos_offset = int(pos_base)
-    if k is None and kc.klen == 0:
+    if k is None and kc.klen - nf == 0 and k_sink is None:
         out.zero_()
         stats[:, 0] = float("-inf")
         stats[:, 1] = 0.0
         return out, stats[:, 0], stats[:, 1]
+    sinks = sink_scores = None
+    if k_sink is not None:
+        sink_scores = torch.empty((H, k_sink.shape[2]), dtype=torch.float16, device=kc.device)
+        sinks = (k_sink, sink_scores, inv)
     if k is not None:
-        kpos = kc.klen
-        vpos = vc.vlen
+        kpos = kc.klen - nf
+        vpos = vc.vlen - nf
         lut_off = kc.lookup_table2 if kc.norm else kc.lookup_table
         ws = ops.decode_prologue(bits, kc.kcache, kc.lookup_table, lut_off, k, kc.outlier_threshold_lower,
                                  kc.outlier_threshold_upper, kc.outliers, kc.outlier_indices, kpos, vc.vcache,
                                  vc.lookup_table, vc.lut, v, vc.outliers, vc.outlier_indices, vpos, q,
                                  kc.num_outliers // 2, kc.outliers_t, kc.outlier_indices_t, kc.lut_ends,
-                                 None if table is kc.lookup_table else table, vc.vnorm_args())
+                                 None if table is kc.lookup_table else table, vc.vnorm_args(), sinks)
         kc.klen += 1
         vc.vlen += 1
     else:
-        ws = ops.score_k_tables(bits, q, table, H)
-    L = kc.klen
+        ws = ops.score_k_tables(bits, q, table, H, sinks)
+    L = kc.klen - nf
+    if L == 0:
+        # only the sink tokens: their softmax and output, no compressed token to score
+        probs = torch.softmax(sink_scores.float(), dim=-1)
+        M = sink_scores.float().max(dim=-1).values
+        stats[:, 0] = M
+        stats[:, 1] = torch.exp(sink_scores.float() - M[:, None]).sum(dim=-1)
+        out.copy_(torch.matmul(probs.half().view(H, 1, -1), v_sink).float().view(1, H, hd))
+        return out, stats[:, 0], stats[:, 1]
     scores = torch.empty((1, H, L), dtype=torch.float32, device=kc.device)
     n_parts = ops._L().kvq_score_k_softmax_parts(bits, L, 1)
     if n_parts <= 0:
@@ -702,10 +720,10 @@ def shard_attention(kc, vc, q, k=None, v=None, pos_base=0, record=None):
     parts = ops.score_k_prepared_softmax(bits, kc.kcache, scores, table, L, kc.rope_theta, pos_offset, ws,
                                          kc.outliers, kc.outlier_indices, inv, n_parts, kc.outliers_t,
                                          kc.outlier_indices_t)
-    ops.softmax_stats(parts, n_parts, H, stats)
-    probs, _ = ops.softmax_finish(scores[0], parts, n_parts, inv)
+    ops.softmax_stats(parts, n_parts, H, stats, sink_scores)
+    probs, _ = ops.softmax_finish(scores[0], parts, n_parts, inv, sink_scores, v_sink, out if v_sink is not None else None)
     ops.mix_v(bits, probs.unsqueeze(0), vc.vcache, out, vc.mix_table(), L, vc.outliers, vc.outlier_indices,
-              accumulate=False)
+              accumulate=v_sink is not None)
     return out, stats[:, 0], stats[:, 1]
 
 
@@ -718,32 +736,62 @@ class HeadShard:
     selected over all H * hd channels (ML:742, 1093-1096) and V's codebook row comes from the token's 22nd largest /
     smallest value (ML:1086-1119).  Every rank therefore sees the WHOLE new token (in a tensor-parallel model: one
     all-gather of the k / v slices) and appends it into a full-width staging column with the ordinary kernels --
-    bit-identical selection and codes on every rank -- and kvq_extract_heads moves its heads' words, the codebook row and
+    bit-identical selection and codes on every rank -- and kvq_extract_heads moves its heads' words, the codebook row(s) and
     its share of the outlier entries (channels rebased, foreign entries zeroed) into the shard's own cache, which the
     ordinary matvec kernels then read with H = n_heads.  Outlier rows stay 42 wide: a shard cannot know in advance how
-    many of a token's outliers fall into its heads.
+    many of a token's outliers fall into its heads.  A decode token is ONE library call (kvq_head_shard_step: append ->
+    extract -> tables -> q.K^T -> softmax -> p.V).
+
+    Carries everything BASELINE config 3 needs (round 5): `first_few_fp16` sink tokens (they shard trivially by head: the
+    caller hands over its heads' slices of the fp16 sink caches) and Q-Norm quantizers (the normalised V codebook rows
+    travel with the extract).
 
     `full_k` / `full_v`: the staging caches (full width, `stage_len` columns; they also own the quantiser tables),
-    `k` / `v`: the shard (QuantK / QuantV over n_heads heads).  Reference outlier format; no fp16 sink tokens."""
+    `k` / `v`: the shard (QuantK / QuantV over n_heads heads).  staging = another HeadShard: share ITS staging buffers
+    (all layers of a model can stage through one set: a decode token uses column 0 only, a prompt goes through in pieces;
+    the tables stay per layer).  Reference outlier format."""
 
     def __init__(self, bits, hidden_size, num_heads, heads, max_position_embeddings, sparsity_threshold=0.99,
-                 rope_theta=10000, device=None, stage_len=64):
+                 rope_theta=10000, device=None, stage_len=64, first_few_fp16=0, staging=None):
         h0, n = int(heads[0]), int(heads[1])
         if not (0 <= h0 and n > 0 and h0 + n <= num_heads):
             raise ValueError("HeadShard: heads (%d, %d) outside 0..%d" % (h0, n, num_heads))
         self.bits, self.h0, self.n_heads, self.num_heads = bits, h0, n, num_heads
         self.head_dim = hidden_size // num_heads
+        self.first_few_fp16 = int(first_few_fp16)
         kw = dict(bits=bits, include_sparse=True, sparsity_threshold=sparsity_threshold, device=device)
-        self.full_k = QuantK(hidden_size=hidden_size, num_heads=num_heads, max_position_embeddings=stage_len,
+        own_len = 64 if staging is not None else stage_len
+        self.full_k = QuantK(hidden_size=hidden_size, num_heads=num_heads, max_position_embeddings=own_len,
                              rope_theta=rope_theta, **kw)
-        self.full_v = QuantV(hidden_size=hidden_size, num_heads=num_heads, max_position_embeddings=stage_len, **kw)
+        self.full_v = QuantV(hidden_size=hidden_size, num_heads=num_heads, max_position_embeddings=own_len, **kw)
+        self._staging = staging
+        if staging is not None:
+            if (staging.bits, staging.num_heads, staging.head_dim) != (bits, num_heads, self.head_dim):
+                raise ValueError("HeadShard: the shared staging caches have another shape")
+            stage_len = staging.stage_len
+            self._adopt_staging()
         width = self.full_k.num_outliers
         self.k = QuantK(hidden_size=n * self.head_dim, num_heads=n, max_position_embeddings=max_position_embeddings,
-                        rope_theta=rope_theta, outlier_width=width, **kw)
+                        rope_theta=rope_theta, outlier_width=width, first_few_fp16=first_few_fp16, **kw)
         self.v = QuantV(hidden_size=n * self.head_dim, num_heads=n, max_position_embeddings=max_position_embeddings,
-                        outlier_width=width, **kw)
+                        outlier_width=width, first_few_fp16=first_few_fp16, **kw)
+        # (the fp16 sink tokens count in klen / vlen as in the reference's attention, ML:1877-1888; the caller owns the
+        #  sink caches and hands its heads' slices to attend())
+        self.k.klen += self.first_few_fp16
+        self.v.vlen += self.first_few_fp16
         self.stage_len = stage_len
         self.device = self.k.device
+        self._layers = None
+
+    def _adopt_staging(self):
+        """point the staging caches' DATA buffers at the shared set (the tables stay this layer's own)"""
+        sk, sv = self._staging.full_k, self._staging.full_v
+        for name in ("kcache", "outliers", "outlier_indices", "outliers_t", "outlier_indices_t"):
+            setattr(self.full_k, name, getattr(sk, name))
+        self.full_k.max_len = sk.max_len
+        for name in ("vcache", "lookup_table", "outliers", "outlier_indices"):
+            setattr(self.full_v, name, getattr(sv, name))
+        self.full_v.max_len = sv.max_len
 
     @property
     def klen(self):
@@ -753,12 +801,15 @@ class HeadShard:
         """the layer's quantizers (deployment/llama.py:186-198) -> the staging caches; the shard reads its heads' slices"""
         if not include_sparse:
             raise ValueError("HeadShard is a Dense-and-Sparse cache")
-        if norm:
-            raise NotImplementedError("HeadShard: Q-Norm quantizers are not carried into the shards (the V rows of the "
-                                      "normalised codebook would have to travel with the extract)")
         self.full_k.load_lookup_table(k_quantizer, include_sparse, sparsity_threshold, norm)
         self.full_v.load_lookup_table(v_quantizer, include_sparse, sparsity_threshold, norm)
-        fk, fv, k, v = self.full_k, self.full_v, self.k, self.v
+        if self._staging is not None and norm:
+            # (the Q-Norm rows of the staged tokens are data like the plain rows: one shared buffer)
+            sv = self._staging.full_v
+            if getattr(sv, "lookup_table2", None) is None or sv.lookup_table2.shape[0] != sv.max_len:
+                sv.lookup_table2 = torch.zeros((sv.max_len, 2 ** self.bits), dtype=torch.float32, device=sv.device)
+            self.full_v.lookup_table2 = sv.lookup_table2
+        fk, k = self.full_k, self.k
         lo, hi = self.h0, self.h0 + self.n_heads
         c0, c1 = lo * self.head_dim, hi * self.head_dim
         k.lut, k.norm, k.include_sparse, k.sparsity_threshold = fk.lut, fk.norm, True, sparsity_threshold
@@ -770,26 +821,27 @@ class HeadShard:
         k.outlier_threshold_lower = fk.outlier_threshold_lower.flatten()[c0:c1].contiguous()
         k.normscale, k.normoffset = fk.normscale, fk.normoffset
         k._step_layer = None
-        for name in ("lut", "norm", "zeropoint", "normscale", "normoffset", "include_sparse", "sparsity_threshold"):
-            if hasattr(fv, name):
-                setattr(v, name, getattr(fv, name))
-        for name in ("_ns", "_no", "_tables_version"):
-            if hasattr(fv, name):
-                setattr(v, name, getattr(fv, name))
+        # the shard's V cache keeps the sorted codebook (and, with Q-Norm, its own rows of the normalised table)
+        self.v.load_lookup_table(v_quantizer, include_sparse, sparsity_threshold, norm)
+        self._layers = None
         return self
 
     def reset(self):
         for c in (self.full_k, self.full_v, self.k, self.v):
             c.reset()
+        self.k.klen += self.first_few_fp16
+        self.v.vlen += self.first_few_fp16
 
     def _extract(self, n):
-        ops.extract_heads(self.bits, self.h0, self.n_heads, self.full_k, self.full_v, self.k, self.v, 0, self.k.klen, n)
+        ops.extract_heads(self.bits, self.h0, self.n_heads, self.full_k, self.full_v, self.k, self.v, 0,
+                          self.k.klen - self.first_few_fp16, n)
         self.k.klen += n
         self.v.vlen += n
 
     def pack(self, k, v):
-        """prompt tokens: k, v [H, hd, S] (whole tokens, pre-RoPE keys) -> the shard's columns, through the staging
-        caches in pieces of stage_len tokens (QuantK / QuantV.parallel_pack: one launch each per piece)"""
+        """prompt tokens (behind the fp16 sink tokens, if any): k, v [H, hd, S] (whole tokens, pre-RoPE keys) -> the shard's
+        columns, through the staging caches in pieces of stage_len tokens (QuantK / QuantV.parallel_pack: one launch each
+        per piece)"""
         S = k.shape[-1]
         for s0 in range(0, S, self.stage_len):
             n = min(self.stage_len, S - s0)
@@ -799,21 +851,42 @@ class HeadShard:
             self.full_v.parallel_pack(v[..., s0:s0 + n])
             self._extract(n)
 
-    def attend(self, q, k, v, record=None):
+    def _layer_structs(self):
+        if self._layers is None:
+            fk, fv, k, v = self.full_k, self.full_v, self.k, self.v
+            f_off = fk.lookup_table2 if fk.norm else fk.lookup_table
+            f_tab = fk.lookup_table2 if (fk.norm and self.bits == 2) else fk.lookup_table
+            s_off = k.lookup_table2 if k.norm else k.lookup_table
+            s_tab = k.lookup_table2 if (k.norm and self.bits == 2) else k.lookup_table
+            self._layers = (ops.make_layer(fk, fv, f_tab, f_off), ops.make_layer(k, v, s_tab, s_off))
+        return self._layers[0][0], self._layers[1][0]
+
+    def attend(self, q, k, v, record=None, k_sink=None, v_sink=None):
         """one decode token: q [H, hd] post-RoPE query (or this shard's [n_heads, hd] slice), k / v [H * hd] the WHOLE new
-        token.  Appends it (staging column 0 -> extract) and returns f32 [1, n_heads, hd]: the complete, normalised attention
-        output of this shard's heads over all cached tokens (a view of `record` when given).  Library launches only."""
-        fk, fv = self.full_k, self.full_v
-        lut_off = fk.lookup_table2 if fk.norm else fk.lookup_table
-        ops.append_k_fused(self.bits, fk.kcache, fk.lookup_table, lut_off, k.flatten().float().contiguous(),
-                           fk.outlier_threshold_lower, fk.outlier_threshold_upper, fk.outliers, fk.outlier_indices,
-                           fk.num_outliers // 2, 0, fk.outliers_t, fk.outlier_indices_t)
-        ops.append_v_fused(self.bits, fv.vcache, fv.lookup_table, fv.lut, v.flatten().float().contiguous(), fv.outliers,
-                           fv.outlier_indices, fv.num_outliers // 2, 0, fv.vnorm_args())
-        self._extract(1)
-        if q.shape[0] == self.num_heads:
+        token (fp16 or fp32, the same dtype as q).  k_sink (f16 [n_heads, 128, n_sink], post-RoPE) / v_sink (f16 [n_heads,
+        n_sink, 128]): this shard's heads of the fp16 sink caches (first_few_fp16 > 0).  Appends the token (staging column 0
+        -> extract) and returns f32 [1, n_heads, hd]: the complete, normalised attention output of this shard's heads over
+        all cached tokens (a view of `record` when given).  ONE library call (kvq_head_shard_step)."""
+        if (k_sink is None) != (self.first_few_fp16 == 0) or (k_sink is None) != (v_sink is None):
+            raise ValueError("HeadShard.attend: pass this shard's k_sink / v_sink exactly when first_few_fp16 > 0")
+        if q.shape[0] == self.num_heads and self.n_heads != self.num_heads:
             q = q[self.h0:self.h0 + self.n_heads]
-        out, _, _ = shard_attention(self.k, self.v, q.contiguous(), pos_base=0, record=record)
+        q = q.contiguous()
+        k, v = k.flatten().contiguous(), v.flatten().contiguous()
+        if record is None:
+            out = torch.empty((1, self.n_heads, self.head_dim), dtype=torch.float32, device=self.device)
+        else:
+            out = record[:self.n_heads * self.head_dim].view(1, self.n_heads, self.head_dim)
+        full, shard = self._layer_structs()
+        sinks = sink_probs = None
+        if k_sink is not None:
+            scores = torch.empty((self.n_heads, k_sink.shape[2]), dtype=torch.float16, device=self.device)
+            sinks = (k_sink, scores, 1.0 / (self.head_dim ** 0.5))
+            sink_probs = torch.empty_like(scores)
+        col = self.k.klen - self.first_few_fp16
+        ops.head_shard_step(full, shard, self.h0, col, q, k, v, out, 1, sinks, v_sink, sink_probs)
+        self.k.klen += 1
+        self.v.vlen += 1
         return out
 
 

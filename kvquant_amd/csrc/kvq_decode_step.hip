@@ -13,6 +13,8 @@
 // without other work in between (the KV-path benchmark).
 #include "kvq_common.h"
 #include "kvq_host.h"
+#include "kvq_ktab.h"
+#include "kvq_shard.h"
 
 namespace kvq {
 
@@ -82,6 +84,34 @@ int kvq_decode_step_events(void *const *events4) {
   return KVQ_OK;
 }
 
+// softmax + p.V (+ slab reduce) of a step, given the raw scores and the softmax partials
+static int step_tail(const kvq_layer *ly, const kvq_sinks *sinks, const uint16_t *v_sink, uint16_t *sink_probs, float *out,
+                     int fuse_softmax, float *scores, float *probs, float *parts, int n_parts, unsigned char *ws,
+                     const StepPlan &p, int64_t L, int n_out, int n_sink, float inv, hipStream_t st) {
+  const int bits = ly->bits, H = ly->H, hd = ly->hd;
+  void *stream = (void *)st;
+  int rc;
+  const float *vrows = ly->v_mix_rows ? ly->v_mix_rows : ly->vlut_rows;
+  const uint16_t *sink_scores = sinks ? sinks->sink_scores : nullptr;
+  if (fuse_softmax) {
+    // (event 2 goes behind the small softmax-merge launch, in front of the p.V kernel: kvq_step_mark_pv below)
+    mark2_pending = true;
+    rc = kvq_mix_v_softmax(bits, scores, parts, n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs, ly->vmat,
+                           out, vrows, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0, ws + p.mix_off, p.mix_b,
+                           stream);
+    if (mark2_pending) { mark2_pending = false; record(2, st); }   // (a route that does not pass the mark: the whole call)
+    record(3, st);
+    return rc;
+  }
+  rc = kvq_softmax_finish(scores, sink_scores, parts, n_parts, probs, sink_probs, H, L, n_sink, inv, v_sink, out, stream);
+  if (rc) return rc;
+  record(2, st);
+  rc = kvq_mix_v(bits, probs, ly->vmat, out, vrows, 1, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out,
+                 v_sink ? 1 : 0, ws + p.mix_off, p.mix_b, stream);
+  record(3, st);
+  return rc;
+}
+
 size_t kvq_decode_step_workspace_bytes(int bits, int H, int hd, int64_t L) {
   if (bits < 2 || bits > 4 || H <= 0 || hd != kHeadDim || L <= 0) return 0;
   return plan_step(bits, H, hd, L).total;
@@ -138,25 +168,101 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
                                        (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) ? KVQ_SCORE_F16_PAIR_TABLES : 0, stream);
   record(1, st);
   if (rc) return rc;
-  const float *vrows = ly->v_mix_rows ? ly->v_mix_rows : ly->vlut_rows;
-  const uint16_t *sink_scores = sinks ? sinks->sink_scores : nullptr;
-  if (fuse_softmax) {
-    // (event 2 goes behind the small softmax-merge launch, in front of the p.V kernel: kvq_step_mark_pv below)
-    mark2_pending = true;
-    rc = kvq_mix_v_softmax(bits, scores, parts, p.n_parts, inv, sink_scores, sink_probs, n_sink, v_sink, probs, ly->vmat,
-                           out, vrows, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out, 0, ws + p.mix_off, p.mix_b,
-                           stream);
-    if (mark2_pending) { mark2_pending = false; record(2, st); }   // (a route that does not pass the mark: the whole call)
-    record(3, st);
-    return rc;
-  }
-  rc = kvq_softmax_finish(scores, sink_scores, parts, p.n_parts, probs, sink_probs, H, L, n_sink, inv, v_sink, out, stream);
+  return step_tail(ly, sinks, v_sink, sink_probs, out, fuse_softmax, scores, probs, parts, p.n_parts, ws, p, L, n_out, n_sink, inv, st);
+}
+
+/* One decode token's attention over a layer's compressed cache WITHOUT an append: query tables (+ fp16 sink scores) ->
+ * q.K^T -> softmax -> p.V over the L cached tokens (the launches of kvq_decode_step behind its prologue).  For shards of
+ * a split stream: the tokens were appended elsewhere (head shard: through the staging cache + kvq_extract_heads), or this
+ * shard does not hold the newest token at all. */
+static int attend_step(const kvq_layer *ly, int64_t L, const void *q, int acts_are_half, const kvq_sinks *sinks,
+                       const uint16_t *v_sink, uint16_t *sink_probs, float *out, int fuse_softmax, void *workspace,
+                       size_t workspace_bytes, void *stream, bool tables_ready) {
+  if (!ly || !q || !out || L <= 0 || L > ly->max_len) return KVQ_EINVAL;
+  if (!ly->kidx_t || !ly->vidx || (ly->koutliers && !ly->kidx) || (ly->koutliers_t && !ly->kidx_t)) return KVQ_EINVAL;
+  if (v_sink && (!sinks || !sink_probs)) return KVQ_EINVAL;
+  const int bits = ly->bits, H = ly->H, hd = ly->hd;
+  const StepPlan p = plan_step(bits, H, hd, L);
+  if (p.n_parts <= 0) return KVQ_EINVAL;
+  if (!workspace || workspace_bytes < p.total || reinterpret_cast<uintptr_t>(workspace) % 256) return KVQ_EWORKSPACE;
+  unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+  float *parts = reinterpret_cast<float *>(ws + p.parts_off);
+  float *scores = reinterpret_cast<float *>(ws + p.scores_off);
+  float *probs = reinterpret_cast<float *>(ws + p.probs_off);
+  const int n_out = 2 * ly->thr_k;
+  const int n_sink = sinks ? sinks->n_sink : 0;
+  const float inv = 1.0f / sqrtf((float)hd);
+  const float *ktab = ly->klut_score ? ly->klut_score : ly->klut;
+  int rc = tables_ready ? KVQ_OK : kvq_score_k_tables(bits, q, acts_are_half, ktab, H, hd, sinks, ws, p.score_ws, stream);
   if (rc) return rc;
-  record(2, st);
-  rc = kvq_mix_v(bits, probs, ly->vmat, out, vrows, 1, H, hd, L, ly->max_len, ly->voutliers, ly->vidx, n_out,
-                 v_sink ? 1 : 0, ws + p.mix_off, p.mix_b, stream);
-  record(3, st);
-  return rc;
+  hipStream_t st = (hipStream_t)stream;
+  struct Clear { ~Clear() { step_events = nullptr; } } clear_events_on_exit;
+  last_route = fuse_softmax ? 1 : 0;
+  record(0, st);
+  rc = kvq_score_k_prepared_softmax_ex(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta, ly->pos_offset,
+                                       ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws, p.score_ws, inv,
+                                       parts, p.n_parts,
+                                       (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) ? KVQ_SCORE_F16_PAIR_TABLES : 0, stream);
+  record(1, st);
+  if (rc) return rc;
+  return step_tail(ly, sinks, v_sink, sink_probs, out, fuse_softmax, scores, probs, parts, p.n_parts, ws, p, L, n_out, n_sink, inv, st);
+}
+
+int kvq_attend_step(const kvq_layer *ly, int64_t L, const void *q, int acts_are_half, const kvq_sinks *sinks,
+                    const uint16_t *v_sink, uint16_t *sink_probs, float *out, int fuse_softmax, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  return attend_step(ly, L, q, acts_are_half, sinks, v_sink, sink_probs, out, fuse_softmax, workspace, workspace_bytes, stream,
+                     false);
+}
+
+/* One decode token through one HEAD SHARD of a layer (kvquant_amd.cache.HeadShard; SURVEY 8e "by head"), one call:
+ * the WHOLE token is appended into column 0 of the full-width staging cache `full` (kvq_append_kv_fused: selection and
+ * codes bit-identical on every rank), heads [h0, h0 + shard->H) of that column are extracted into column `col` of the
+ * shard's cache (kvq_extract_heads) and the shard's heads attend over its col + 1 tokens (kvq_attend_step).  q: the
+ * shard's heads of the RoPE'd query [shard->H][128]; k, v: the whole token [full->H * hd]; sinks / v_sink / sink_probs: the
+ * shard's heads of the fp16 sink caches.  out f32 [shard->H][hd]. */
+int kvq_head_shard_step(const kvq_layer *full, const kvq_layer *shard, int h0, int64_t col, const void *q, const void *k,
+                        const void *v, int acts_are_half, const kvq_sinks *sinks, const uint16_t *v_sink,
+                        uint16_t *sink_probs, float *out, int fuse_softmax, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+  if (!full || !shard || h0 < 0 || h0 + shard->H > full->H || full->bits != shard->bits || full->hd != shard->hd ||
+      full->thr_k != shard->thr_k || col < 0 || col >= shard->max_len)
+    return KVQ_EINVAL;
+  if (!full->koutliers || !full->voutliers || !shard->koutliers || !shard->voutliers) return KVQ_EINVAL;   // (reference outlier format)
+  int rc = kvq_append_kv_fused(full, 0, k, v, acts_are_half, stream);
+  if (rc) return rc;
+  // the extract of the staged column and the shard's query tables (+ fp16 sink scores) as ONE launch
+  if (!q || !workspace || reinterpret_cast<uintptr_t>(workspace) % 256 ||
+      workspace_bytes < kvq_decode_step_workspace_bytes(shard->bits, shard->H, shard->hd, col + 1))
+    return KVQ_EWORKSPACE;
+  if (sinks != nullptr && sinks->n_sink > 0 && (!sinks->k_sink || !sinks->sink_scores)) return KVQ_EINVAL;
+  const kvq_vopts *vn = full->vnorm;
+  const kvq_vopts *sn = shard->vnorm;
+  ExtractArgs a;
+  fill_extract_args(a, full->bits, full->hd, h0, shard->H, 2 * full->thr_k, full->kmat, full->vmat, full->max_len, 0,
+                    full->koutliers, full->kidx, full->voutliers, full->vidx, full->vlut_rows, shard->kmat, shard->vmat,
+                    shard->max_len, col, shard->koutliers, shard->kidx, shard->koutliers_t, shard->kidx_t, shard->voutliers,
+                    shard->vidx, shard->vlut_rows, (vn && sn) ? vn->lut_rows2 : nullptr, (vn && sn) ? sn->lut_rows2 : nullptr, 1);
+  const int bits = shard->bits, Hs = shard->H;
+  unsigned char *tab = reinterpret_cast<unsigned char *>(workspace);
+  const size_t qoff = bits == 4 ? ktab_q_offset<4>(1, Hs) : (bits == 3 ? ktab_q_offset<3>(1, Hs) : ktab_q_offset<2>(1, Hs));
+  a.n_tab = Hs;
+  a.lut = shard->klut_score ? shard->klut_score : shard->klut;
+  a.q = q;
+  a.q_is_half = acts_are_half;
+  a.tab = tab;
+  a.q32 = reinterpret_cast<float *>(tab + qoff);
+  a.pair_tab = bits == 3 ? tab + ktab_pair_offset<3>(1, Hs) : nullptr;
+  if (sinks != nullptr && sinks->n_sink > 0) {
+    a.k_sink = reinterpret_cast<const __half *>(sinks->k_sink);
+    a.sink_scores = reinterpret_cast<__half *>(sinks->sink_scores);
+    a.n_sink = sinks->n_sink;
+    a.sink_inv = sinks->inv_sqrt_hd;
+  }
+  rc = launch_extract_fused(a, (hipStream_t)stream);
+  if (rc) return rc;
+  return attend_step(shard, col + 1, q, acts_are_half, sinks, v_sink, sink_probs, out, fuse_softmax, workspace, workspace_bytes,
+                     stream, true);
 }
 
 int kvq_decode_steps(int n_layers, const kvq_layer *layers, int64_t col, const void *const *q, const void *const *k,

@@ -752,4 +752,44 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
   return check_launch();
 }
 
+/* K append | V append of one token as ONE launch (the two selection workgroups of kvq_decode_prologue without the table
+ * roles): for callers that build the score tables elsewhere -- the head-sharded step appends the whole token into its
+ * full-width staging column, then extracts (kvq_head_shard_step). */
+int kvq_append_kv_fused(const kvq_layer *ly, int64_t col, const void *k, const void *v, int acts_are_half, void *stream) {
+  if (!ly || !k || !v || col < 0 || col >= ly->max_len || ly->bits < 2 || ly->bits > 4) return KVQ_EINVAL;
+  PrologueArgs P;
+  P.k = k_args(ly->kmat, ly->klut, ly->klut_off, k, acts_are_half, ly->klo, ly->khi, ly->koutliers, ly->kidx, ly->thr_k,
+               ly->H, ly->hd, ly->max_len, col, ly->koutliers_t, ly->kidx_t);
+  P.k.lut_ends = ly->klut_ends;
+  P.v = v_args(ly->vmat, ly->vlut_rows, ly->vlut_sorted, v, acts_are_half, ly->voutliers, ly->vidx, ly->thr_k, ly->H, ly->hd,
+               ly->max_len, col, ly->vnorm);
+  int rc = check_append(false, P.k, ly->H, ly->hd);
+  if (rc) return rc;
+  rc = check_append(true, P.v, ly->H, ly->hd);
+  if (rc) return rc;
+  P.klut = ly->klut;
+  P.q = nullptr;
+  P.q_is_half = 0;
+  P.tab = nullptr;
+  P.q32 = nullptr;
+  P.pair_tab = nullptr;
+  P.H = ly->H;
+  P.k_sink = nullptr;
+  P.sink_scores = nullptr;
+  P.n_sink = 0;
+  P.sink_inv = 0.f;
+#if KVQ_TRACE
+  P.k.trace = nullptr;
+  P.v.trace = nullptr;
+#endif
+  dim3 grid(2), block(kSelThreads);          // (blocks 0 and 1 of the prologue kernel: the two appends)
+  hipStream_t st = (hipStream_t)stream;
+  switch (ly->bits) {
+    case 4: decode_prologue_kernel<4><<<grid, block, 0, st>>>(P); break;
+    case 3: decode_prologue_kernel<3><<<grid, block, 0, st>>>(P); break;
+    default: decode_prologue_kernel<2><<<grid, block, 0, st>>>(P); break;
+  }
+  return check_launch();
+}
+
 }  // extern "C"

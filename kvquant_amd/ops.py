@@ -533,22 +533,40 @@ def mix_v_softmax(bits, scores, parts, n_parts, inv_sqrt_hd, mat, mul, lut_rows,
 
 
 # ---- token-sharded single stream ---------------------------------------------------------------------------------
-def score_k_tables(bits, q, lut, H):
+def _sinks_struct(sinks, H):
+    """(k_sink f16 [H, 128, n_sink], sink_scores f16 [H, n_sink] (out), inv_sqrt_hd) -> struct kvq_sinks, or None"""
+    if sinks is None:
+        return None
+    k_sink, sink_scores, inv = sinks
+    n_sink = sink_scores.shape[1]
+    if tuple(k_sink.shape) != (H, 128, n_sink) or sink_scores.shape[0] != H:
+        raise ValueError("sinks: k_sink [H, 128, n_sink] and sink_scores [H, n_sink] expected")
+    return _lib.Sinks(_chk(k_sink, torch.float16, "k_sink"), _chk(sink_scores, torch.float16, "sink_scores"), n_sink, float(inv))
+
+
+def score_k_tables(bits, q, lut, H, sinks=None):
     """query-premultiplied K tables into the score workspace without an append (kvq_score_k_tables); returns the
-    workspace tensor for score_k_prepared[_softmax]"""
+    workspace tensor for score_k_prepared[_softmax].  sinks = (k_sink, sink_scores (out), inv_sqrt_hd): the scaled
+    scores of the fp16 sink tokens this shard holds are written too."""
     qp, qh = _act(q, "q")
+    sk = _sinks_struct(sinks, H)
     with _Dev(lut):
         nbytes = _L().kvq_score_k_workspace_bytes(bits, 1, H)
         ws = _workspace(lut.device, nbytes, slot="score")
-        _lib.check(_L().kvq_score_k_tables(bits, qp, qh, _f(lut, "lookup_table"), H, 128, ws.data_ptr(), ws.numel(),
+        _lib.check(_L().kvq_score_k_tables(bits, qp, qh, _f(lut, "lookup_table"), H, 128,
+                                           None if sk is None else ctypes.byref(sk), ws.data_ptr(), ws.numel(),
                                            _stream()), "kvq_score_k_tables")
     return ws
 
 
-def softmax_stats(parts, n_parts, H, stats):
-    """(max, normaliser) of every head's scaled scores from the score kernel's partials -> stats f32 [H, 2]"""
+def softmax_stats(parts, n_parts, H, stats, sink_scores=None):
+    """(max, normaliser) of every head's scaled scores from the score kernel's partials (+ the fp16 sink tokens' scaled
+    scores f16 [H, n_sink] of the shard that holds them) -> stats f32 [H, 2]"""
+    n_sink = 0 if sink_scores is None else sink_scores.shape[1]
     with _Dev(stats):
-        _lib.check(_L().kvq_softmax_stats(parts.data_ptr(), int(n_parts), int(H), _f(stats, "stats"), _stream()),
+        _lib.check(_L().kvq_softmax_stats(parts.data_ptr(), int(n_parts),
+                                          None if n_sink == 0 else _chk(sink_scores, torch.float16, "sink_scores"), n_sink,
+                                          int(H), _f(stats, "stats"), _stream()),
                    "kvq_softmax_stats")
 
 
@@ -587,7 +605,10 @@ def extract_heads(bits, h0, n_heads, src_k, src_v, dst_k, dst_v, src_col, dst_co
             _io(getattr(dst_k, "outlier_indices_t", None) if sparse else None, "dst k outlier_indices_t"),
             _fo(dst_v.outliers if sparse else None, "dst v outliers"),
             _io(dst_v.outlier_indices if sparse else None, "dst v outlier_indices"),
-            _f(dst_v.lookup_table, "dst v lookup_table"), int(n), _stream()), "kvq_extract_heads")
+            _f(dst_v.lookup_table, "dst v lookup_table"),
+            None if src_v.lookup_table2 is None else _f(src_v.lookup_table2, "src v lookup_table2"),
+            None if src_v.lookup_table2 is None else _f(dst_v.lookup_table2, "dst v lookup_table2"),
+            int(n), _stream()), "kvq_extract_heads")
 
 
 # ---- one decode token through one layer, one library call -----------------------------------------------------------
@@ -662,3 +683,28 @@ def prefill_attention(q, k, v, softmax_scale=None):
                                              v.stride(1), out.stride(1), out.stride(0), scale, _stream()),
                    "kvq_prefill_attention")
     return out.view(S, H * hd)
+
+
+def _step_ws(dev, bits, H, hd, L):
+    nbytes = _L().kvq_decode_step_workspace_bytes(bits, H, hd, int(L))
+    ws = _workspace(dev, nbytes + 256, slot="step")
+    return (ws.data_ptr() + 255) & ~255, ws.numel() - 256, ws
+
+
+def head_shard_step(full_layer, shard_layer, h0, col, q, k, v, out, fuse_softmax, sinks=None, v_sink=None, sink_probs=None):
+    """kvq_head_shard_step: whole-token append into the staging cache -> extract of the shard's heads -> the shard's
+    attention, ONE library call.  q [n_heads, 128] (the shard's heads), k, v [C] (the whole token): all fp16 or all fp32;
+    out f32 [1, n_heads, hd]; sinks = (k_sink, sink_scores (out), inv_sqrt_hd) of the shard's heads."""
+    kp, kh = _act(k, "k")
+    vp, vh = _act(v, "v")
+    qp, qh = _act(q, "q")
+    if not (kh == vh == qh):
+        raise ValueError("q, k, v must share one dtype (fp32 or fp16)")
+    sk = _sinks_struct(sinks, shard_layer.H)
+    with _Dev(out):
+        base, nb, keep = _step_ws(out.device, shard_layer.bits, shard_layer.H, shard_layer.hd, int(col) + 1)
+        _lib.check(_L().kvq_head_shard_step(
+            ctypes.byref(full_layer), ctypes.byref(shard_layer), int(h0), int(col), qp, kp, vp, kh,
+            None if sk is None else ctypes.byref(sk), None if v_sink is None else _chk(v_sink, torch.float16, "v_sink"),
+            None if sink_probs is None else sink_probs.data_ptr(), _f(out, "out"), int(fuse_softmax), base, nb, _stream()),
+            "kvq_head_shard_step")

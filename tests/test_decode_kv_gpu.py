@@ -297,10 +297,61 @@ def test_token_sharded_attention_matches_unsharded(bits, S, split):
         scale_o = ref.abs().max().item() + 1e-6
         assert (out - ref).abs().max().item() <= 2e-3 * scale_o, step
         assert (out - out_t).abs().max().item() <= 1e-5 * scale_o, step
-    with pytest.raises(ValueError):          # fp16 sink tokens are not part of the sharded path (no silent drop)
+    with pytest.raises(ValueError):          # a cache that counts sink tokens it was never given (klen < first_few_fp16)
         kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=64, include_sparse=True,
                   sparsity_threshold=0.99, first_few_fp16=5, device=dev)
         shard_attention(QuantK(rope_theta=10000.0, **kw), QuantV(**kw), q)
+
+
+@pytest.mark.parametrize("bits,S,split,sinks", [(3, 900, 400, 5), (4, 300, 0, 3)])
+def test_token_sharded_attention_with_sink_tokens(bits, S, split, sinks):
+    """BASELINE config 3 on a token-sharded context (round 5): the shard that holds the START of the context also gets the
+    fp16 attention-sink tokens (first_few_fp16, ML:1464-1466) -- their scores enter its softmax and its (max, normaliser),
+    their values its output -- and the merged result equals decode_kv(k_sink=, v_sink=) on the unsharded cache.
+    split = 0: the first shard holds ONLY the sink tokens."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd import ops
+    from kvquant_amd.cache import QuantK, QuantV, decode_kv, shard_attention, shard_record_floats
+    dev = torch.device("cuda:0")
+    H, HD, C = decode_check.H, decode_check.HD, decode_check.C
+    quant, scale, shift = decode_check.quantizer(bits, seed=5 + bits)
+    g = torch.Generator().manual_seed(S + bits)
+    k = (torch.randn(C, S, generator=g) * scale[:, None] * 1.3 + shift[:, None]).reshape(H, HD, S).to(dev)
+    v = (torch.randn(C, S, generator=g) * 1.7).reshape(H, HD, S).to(dev)
+    k_sink = (torch.randn(H, HD, sinks, generator=g) * 0.5).half().to(dev)
+    v_sink = torch.randn(H, sinks, HD, generator=g).half().to(dev)
+
+    def make(ks, vs, max_len, nf):
+        kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+                  sparsity_threshold=0.99, first_few_fp16=nf, device=dev)
+        kc, vc = QuantK(rope_theta=10000.0, **kw), QuantV(**kw)
+        kc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        vc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99)
+        kc.klen += nf
+        vc.vlen += nf
+        if ks.shape[-1]:
+            kc.parallel_pack(ks.contiguous())
+            vc.parallel_pack(vs.contiguous())
+        return kc, vc
+
+    full = make(k, v, (S + 64 + 63) // 64 * 64, sinks)
+    s0 = make(k[:, :, :split], v[:, :, :split], (split + 64 + 63) // 64 * 64, 0)          # plain shard caches; the sinks come per call
+    s1 = make(k[:, :, split:], v[:, :, split:], (S - split + 64 + 63) // 64 * 64, 0)
+    nrec = shard_record_floats(H, HD)
+    for step in range(2):
+        q = torch.randn(H, HD, generator=g).half().to(dev)
+        kn = (torch.randn(C, generator=g) * scale * 1.3 + shift).half().to(dev)
+        vn = (torch.randn(C, generator=g) * 1.7).half().to(dev)
+        ref, _ = decode_kv(full[0], full[1], q, kn, vn, k_sink=k_sink, v_sink=v_sink)
+        gathered = torch.empty(2 * nrec, device=dev)
+        shard_attention(s0[0], s0[1], q, pos_base=sinks, record=gathered[:nrec], k_sink=k_sink, v_sink=v_sink)
+        shard_attention(s1[0], s1[1], q, kn, vn, pos_base=sinks + split, record=gathered[nrec:])
+        out = torch.empty(1, H, HD, device=dev)
+        ops.combine_shards(gathered, 2, H, HD, out)
+        torch.cuda.synchronize()
+        scale_o = ref.abs().max().item() + 1e-6
+        assert (out - ref).abs().max().item() <= 2e-3 * scale_o, (step, (out - ref).abs().max().item() / scale_o)
 
 
 @pytest.mark.parametrize("bits,sinks,L0", [(4, 0, 40), (3, 5, 300), (2, 0, 40)])

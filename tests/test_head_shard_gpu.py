@@ -28,23 +28,24 @@ def _shards(bits, seed, max_len, dev, prompt, splits, stage_len=64):
     return out
 
 
-def _check_state(kc, vc, shards, L):
-    """the shards' caches against the unsharded ones, columns [0, L)"""
-    W = kc.kcache.shape[1]
+def _check_state(kc, vc, shards, L, sinks=0):
+    """the shards' caches against the head slices of the unsharded ones as the ORACLE cuts them (oracle.glue.slice_heads: the
+    checker's own statement of the extract, evaluated on CPU copies), columns [0, L)"""
+    from oracle import glue
+    full = [t[..., :L].cpu() if t.dim() == 3 else t[:L].cpu() for t in
+            (kc.kcache, vc.vcache, vc.lookup_table, kc.outliers, kc.outlier_indices, vc.outliers, vc.outlier_indices)]
     for hs in shards:
         h0, n = hs.h0, hs.n_heads
-        assert hs.k.klen == L and hs.v.vlen == L
-        assert torch.equal(hs.k.kcache[:, :, :L], kc.kcache[h0:h0 + n, :, :L])
-        assert torch.equal(hs.v.vcache[:, :, :L], vc.vcache[h0:h0 + n, :, :L])
-        assert torch.equal(hs.v.lookup_table[:L], vc.lookup_table[:L])
-        c0, c1 = h0 * HD, (h0 + n) * HD
-        for full_val, full_idx, sh_val, sh_idx in ((kc.outliers, kc.outlier_indices, hs.k.outliers, hs.k.outlier_indices),
-                                                   (vc.outliers, vc.outlier_indices, hs.v.outliers, hs.v.outlier_indices)):
-            fv, fi = full_val[:L], full_idx[:L]
-            own = (fi >= c0) & (fi < c1)
-            assert torch.equal(sh_val[:L], torch.where(own, fv, torch.zeros_like(fv)))
-            exp_idx = torch.where(own, fi - c0, torch.where(fi < c0, torch.zeros_like(fi), torch.full_like(fi, c1 - c0 - 1)))
-            assert torch.equal(sh_idx[:L], exp_idx)
+        assert hs.k.klen == L + sinks and hs.v.vlen == L + sinks
+        kw, vw, rows, (kv, ki), (vv, vi) = glue.slice_heads(*full, h0, n, HD)
+        assert torch.equal(hs.k.kcache[:, :, :L].cpu(), kw)
+        assert torch.equal(hs.v.vcache[:, :, :L].cpu(), vw)
+        assert torch.equal(hs.v.lookup_table[:L].cpu(), rows)
+        if vc.lookup_table2 is not None:
+            assert torch.equal(hs.v.lookup_table2[:L], vc.lookup_table2[:L])
+        for want_v, want_i, sh_val, sh_idx in ((kv, ki, hs.k.outliers, hs.k.outlier_indices), (vv, vi, hs.v.outliers, hs.v.outlier_indices)):
+            assert torch.equal(sh_val[:L].cpu().view(torch.int32), want_v.view(torch.int32))
+            assert torch.equal(sh_idx[:L].cpu(), want_i)
             assert bool((sh_idx[:L, 1:] >= sh_idx[:L, :-1]).all())          # rows stay sorted by channel
         assert torch.equal(hs.k.outliers_t[:, :L], hs.k.outliers[:L].t())
         assert torch.equal(hs.k.outlier_indices_t[:, :L], hs.k.outlier_indices[:L].t())
@@ -163,3 +164,56 @@ def test_extract_heads_argument_checks():
     with pytest.raises(ValueError):
         ops.extract_heads(4, 8, 4, hs.full_k, hs.full_v, hs.k, hs.v, 0, 0, 1)                # the shard holds 8 heads, not 4
     assert hs.k.klen == 0 and not bool(hs.k.kcache.any())
+
+
+@pytest.mark.parametrize("bits,norm,sinks,shared_stage", [(3, False, 5, False), (3, False, 5, True), (2, True, 0, False), (4, True, 3, True)])
+def test_head_shards_carry_sinks_and_qnorm(bits, norm, sinks, shared_stage):
+    """BASELINE config 3 on a head-sharded layer (round 5): nuq3 + 5 fp16 attention-sink tokens -- every shard gets its heads'
+    slices of the fp16 sink caches and its output must be the unsharded decode_kv rows of its heads -- and Q-Norm
+    quantizers (the normalised V codebook rows travel with the extract); optionally all shards stage through ONE shared
+    set of staging buffers.  One library call per shard and token (kvq_head_shard_step)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from kvquant_amd.cache import HeadShard, QuantK, QuantV, decode_kv
+    from tests import decode_check, util
+    util.sync_oracle_freqs(10000.0)
+    dev = torch.device("cuda:0")
+    S, steps, max_len = 150, 3, 512
+    quant, scale, shift = decode_check.quantizer(bits, seed=11)
+    if norm:      # (upper, lower, [centroids], normscale, normoffset), SQ:550-555
+        quant = tuple(quant) + (torch.tensor(1.07), torch.tensor(-0.02))
+    prompt = _prompt(31, S, scale, shift)
+    kw = dict(bits=bits, hidden_size=C, num_heads=H, max_position_embeddings=max_len, include_sparse=True,
+              sparsity_threshold=0.99, first_few_fp16=sinks, device=dev)
+    kc, vc = QuantK(rope_theta=10000.0, **kw), QuantV(**kw)
+    kc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99, norm=norm)
+    vc.load_lookup_table(quant, include_sparse=True, sparsity_threshold=0.99, norm=norm)
+    kc.klen += sinks
+    vc.vlen += sinks
+    kc.parallel_pack(prompt[0].to(dev).contiguous())
+    vc.parallel_pack(prompt[1].to(dev).contiguous())
+    g = torch.Generator().manual_seed(5)
+    k_sink = (torch.randn(H, HD, sinks, generator=g) * 0.5).half().to(dev) if sinks else None
+    v_sink = torch.randn(H, sinks, HD, generator=g).half().to(dev) if sinks else None
+    splits = [(0, 8), (8, 16), (24, 8)]
+    shards, stage = [], None
+    for h0, n in splits:
+        hs = HeadShard(bits, C, H, (h0, n), max_len, device=dev, stage_len=64, first_few_fp16=sinks,
+                       staging=stage if shared_stage else None)
+        if shared_stage and stage is None:
+            stage = hs
+        hs.load_lookup_table(quant, quant, norm=norm)
+        hs.pack(prompt[0].to(dev), prompt[1].to(dev))
+        shards.append(hs)
+    _check_state(kc, vc, shards, S, sinks)
+    q, k, v = _tokens(77, steps, scale, shift)
+    for st in range(steps):
+        ref, _ = decode_kv(kc, vc, q[st].to(dev), k[st].to(dev), v[st].to(dev), k_sink=k_sink, v_sink=v_sink)
+        scale_ref = ref.abs().max().item() + 1e-6
+        for hs in shards:
+            sl = slice(hs.h0, hs.h0 + hs.n_heads)
+            out = hs.attend(q[st].to(dev), k[st].to(dev), v[st].to(dev),
+                            k_sink=None if not sinks else k_sink[sl].contiguous(),
+                            v_sink=None if not sinks else v_sink[sl].contiguous())
+            assert (out - ref[:, sl]).abs().max().item() <= 1e-3 * scale_ref, (bits, st, hs.h0)
+        _check_state(kc, vc, shards, S + st + 1, sinks)
