@@ -26,8 +26,11 @@ constexpr int kTNT = kTT * kTG;
 constexpr int kTE = 16;         // channels per lane in phase 2: C <= 4096
 constexpr int kTC = kTG * kTE;  // 4096
 
+constexpr int kTHC = 4;         // copies of a selection histogram, lanes spread over them: same-address LDS atomics serialise
+                                // (the first pass puts a token's 4096 keys into ~10 bins; round 4 measured 46 % / 54 % of the
+                                // kernel's LDS-active cycles as bank conflicts with ONE copy; the LDS is there: 150 of 160 KB)
 struct TiledSel {
-  uint32_t hist[2][2][256];     // [pass parity][side][digit]
+  uint32_t hist[2][2][kTHC][256];     // [pass parity][side][copy][digit]
   uint32_t prefix[2], krem[2];
   uint32_t scan[kTG / 64];
   float vrow[16], vrow2[16];
@@ -35,7 +38,7 @@ struct TiledSel {
 
 struct TiledShared {
   float ss[kTT][kTC + kTC / 32];          // K: rescaled values, V: values; channel c at c + c/32
-  unsigned char cb[kTT][kTC];             // codes
+  unsigned char cb[kTT][kTC + 16];        // codes (+16: the four tokens of a 32-channel group in different banks for the pack's reads)
   TiledSel sel[kTT];
   int any_cut;
 };
@@ -66,10 +69,11 @@ __device__ __forceinline__ void group_select_both(const uint32_t (&key)[kTE], co
     sh.prefix[tg] = 0;
     sh.krem[tg] = k;
   }
-  for (int i = tg; i < 512; i += kTG) (&sh.hist[1][0][0])[i] = 0;   // (the first pass is pass 3: parity 1)
+  for (int i = tg; i < 512 * kTHC; i += kTG) (&sh.hist[1][0][0][0])[i] = 0;   // (the first pass is pass 3: parity 1)
   __syncthreads();
   for (int pass = 3; pass >= 0; pass--) {
-    uint32_t (*hist)[256] = sh.hist[pass & 1];
+    uint32_t (*hist)[kTHC][256] = sh.hist[pass & 1];
+    const int cp = tg & (kTHC - 1);
     const uint32_t p0 = sh.prefix[0], p1 = sh.prefix[1];
 #pragma unroll
     for (int e = 0; e < kTE; e++) {
@@ -77,8 +81,8 @@ __device__ __forceinline__ void group_select_both(const uint32_t (&key)[kTE], co
       const uint32_t kk = key[e];
       const uint32_t hi = (pass == 3) ? 0u : (kk >> (8 * (pass + 1)));
       const uint32_t d = (kk >> (8 * pass)) & 0xffu;
-      if (hi == p0) atomicAdd(&hist[0][d], 1u);                       // (first pass: both sides count every element)
-      if (pass != 3 && hi == p1) atomicAdd(&hist[1][d], 1u);
+      if (hi == p0) atomicAdd(&hist[0][cp][d], 1u);                   // (first pass: both sides count every element)
+      if (pass != 3 && hi == p1) atomicAdd(&hist[1][cp][d], 1u);
     }
     __syncthreads();
     const int wave = tg >> 6, lane = tg & 63;
@@ -90,7 +94,9 @@ __device__ __forceinline__ void group_select_both(const uint32_t (&key)[kTE], co
       for (int j = 0; j < 4; j++) {
         const int pos = lane * 4 + j;
         const int bin = side == 0 ? 255 - pos : pos;
-        c[j] = hist[pass == 3 ? 0 : side][bin];
+        c[j] = 0;
+#pragma unroll
+        for (int q = 0; q < kTHC; q++) c[j] += hist[pass == 3 ? 0 : side][q][bin];
         s += c[j];
       }
       const uint32_t inc = wave_incl_scan(s);
@@ -110,7 +116,7 @@ __device__ __forceinline__ void group_select_both(const uint32_t (&key)[kTE], co
         }
       }
     } else if (pass > 0) {
-      for (int i = tg - 128; i < 512; i += kTG - 128) (&sh.hist[(pass - 1) & 1][0][0])[i] = 0;
+      for (int i = tg - 128; i < 512 * kTHC; i += kTG - 128) (&sh.hist[(pass - 1) & 1][0][0][0])[i] = 0;
     }
     __syncthreads();
   }
@@ -197,7 +203,12 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
   group_select_both(key, ok, ksel, ts, tg, T, gtc);
 
   // membership: strictly beyond the threshold, plus the first ties in channel order (fused_append_body)
-  const uint32_t eq_hi = ts.hist[0][0][T[0] & 0xffu], eq_lo = ts.hist[0][1][T[1] & 0xffu];
+  uint32_t eq_hi = 0, eq_lo = 0;
+#pragma unroll
+  for (int q = 0; q < kTHC; q++) {
+    eq_hi += ts.hist[0][0][q][T[0] & 0xffu];
+    eq_lo += ts.hist[0][1][q][T[1] & 0xffu];
+  }
   const uint32_t want_hi = (uint32_t)thr_k - gtc[0], want_lo = (uint32_t)thr_k - gtc[1];
   const bool cut = !((want_hi == 0 || eq_hi == want_hi) && (want_lo == 0 || eq_lo == want_lo));   // (group-uniform)
   if (cut && tg == 0) sh.any_cut = 1;
@@ -252,11 +263,28 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
     float row[N];
 #pragma unroll
     for (int v = 0; v < N; v++) row[v] = ts.vrow[v];
+    // (the lane's 16 codes leave as four words when its channels are 16 whole ones -- C = 4096 --: byte stores of
+    //  neighbouring lanes 16 bytes apart are a 4-way bank conflict each)
+    uint32_t cw[kTE / 4];
+#pragma unroll
+    for (int i = 0; i < kTE / 4; i++) cw[i] = 0;
 #pragma unroll
     for (int e = 0; e < kTE; e++) {
       if (!ok[e]) continue;
       const bool clip = A.tie_quirk ? (sel[e] < vmin || sel[e] > vmax) : (in_hi[e] || in_lo[e]);
-      sh.cb[gt_][c0 + e] = (unsigned char)(clip ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, sel[e]));
+      const unsigned code = clip ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, sel[e]);
+      if (per == kTE) cw[e >> 2] |= code << (8 * (e & 3));
+      else sh.cb[gt_][c0 + e] = (unsigned char)code;
+    }
+    if (per == kTE) {
+      const bool full = c0 + kTE <= C;
+      if (full) {
+        *reinterpret_cast<uint4 *>(&sh.cb[gt_][c0]) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < kTE; e++)
+          if (ok[e]) sh.cb[gt_][c0 + e] = (unsigned char)(cw[e >> 2] >> (8 * (e & 3)));
+      }
     }
   }
 

@@ -96,6 +96,82 @@ class FakeQuantLinear(nn.Module):
         return out.reshape(shape)
 
 
+class DeployRuleLinear(nn.Module):
+    """k_proj / v_proj followed by the DEPLOYMENT classes' quantise -> dequantise of every token, from the oracle's
+    restatement of their glue (oracle.glue: build_k_lut, k_outlier_rows, v_token_rows; ML:437-501, 706-751, 1086-1176):
+    K: nearest code against the per-channel table of fp16-rounded thresholds, the 21 + 21 capped outliers of the
+    RESCALED token kept as residuals to the end codes;  V: per-token thresholds = the 22nd largest / smallest value,
+    codebook row lut * sf + off, values strictly outside clipped to the zero-point code, the 21 + 21 extreme values
+    kept as residuals to it (the reference's tie quirk included).  This is what the kernels must reproduce to rounding
+    -- unlike the simulated path, whose V outliers come from a quantile (SQ:95-108)."""
+
+    def __init__(self, lin, quantizer, bits, is_k, heads, first_few_fp16, norm):
+        super().__init__()
+        self.lin, self.q, self.bits, self.is_k, self.heads, self.ff, self.norm = lin, quantizer, bits, is_k, heads, first_few_fp16, norm
+
+    def forward(self, x):
+        from oracle import glue
+        y = self.lin(x.half())
+        shape = y.shape
+        y2 = y.reshape(-1, shape[-1]).float()
+        dev, C, n, thr_k = y2.device, y2.shape[1], 2 ** self.bits, glue.threshold_k(0.99, y2.shape[1])
+        if self.is_k:
+            t = glue.build_k_lut(self.q, self.bits, self.heads, C // self.heads, norm=self.norm)
+            lut = t["lookup_table"].reshape(C, n).to(dev)
+            lut_off = (t["lookup_table2"] if self.norm else t["lookup_table"]).reshape(C, n).to(dev)
+            lut_deq = (t["lookup_table2"] if (self.norm and self.bits == 2) else t["lookup_table"]).reshape(C, n).to(dev)
+            up, lo = t["upper"].to(dev), t["lower"].to(dev)
+            code = (lut.unsqueeze(0) - y2.unsqueeze(-1)).abs().argmin(dim=-1)            # first minimum (KCU:1230-1237)
+            deq = torch.gather(lut_deq.unsqueeze(0).expand(y2.shape[0], -1, -1), 2, code.unsqueeze(-1)).squeeze(-1)
+            resc = (y2 - (up + lo) / 2) / ((up - lo) / 2)                                # KCU:1759-1764
+            vals, idx = glue.k_outlier_rows(y2.cpu(), resc.cpu(), lut_off.cpu(), self.bits, thr_k)
+            out = deq.clone()
+            out.scatter_add_(1, idx.long().to(dev), vals.to(dev))
+        else:
+            lut_sorted = torch.as_tensor(self.q[2][0]).squeeze(-1).float().sort().values.to(dev)
+            r = glue.v_token_rows(y2.cpu(), lut_sorted.cpu(), self.bits, thr_k)
+            rows = r["lut_rows"].to(dev)
+            if self.norm:
+                ns, no = torch.as_tensor(self.q[3]).float().to(dev), torch.as_tensor(self.q[4]).float().to(dev)
+                sf, off = (r["maxval"] - r["minval"]).to(dev) / 2, (r["maxval"] + r["minval"]).to(dev) / 2
+                rows2 = (lut_sorted * ns + no).unsqueeze(0) * sf.unsqueeze(-1) + off.unsqueeze(-1)
+            deq_rows = rows2 if (self.norm and self.bits == 2) else rows
+            z = glue.ZERO_CODE[self.bits]
+            code = (rows.unsqueeze(1) - y2.unsqueeze(-1)).abs().argmin(dim=-1)
+            clip = (y2 < r["minval"].to(dev).unsqueeze(-1)) | (y2 > r["maxval"].to(dev).unsqueeze(-1))      # KCU:2084 (strict)
+            code = torch.where(clip, torch.full_like(code, z), code)
+            out = torch.gather(deq_rows, 1, code).clone()
+            vals = r["vals"].to(dev)
+            if self.norm and self.bits == 2:      # residuals refer to the table the kernel dequantises with (ML:1153-1156)
+                vals = vals + (rows[:, z] - rows2[:, z]).unsqueeze(-1)
+            out.scatter_add_(1, r["idx"].long().to(dev), vals)
+        if self.ff > 0:
+            out[:self.ff] = y2[:self.ff]                                                  # fp16 sink tokens stay as they are
+        return out.reshape(shape)
+
+
+@torch.no_grad()
+def deploy_rule_ppl(model, ids, quantizers, bits, first_few_fp16=-1, norm=False, n_prompt=0, scores64=False):
+    """the deployment classes' OWN quantisation (oracle.glue restatement) + the deployment path's attention arithmetic, in
+    plain torch: the comparator the kernel path has to match to rounding (bar 2e-4 relative perplexity)"""
+    import types
+    m = copy.deepcopy(model)
+    cfg = m.config
+    theta = getattr(cfg, "rope_theta", None) or (getattr(cfg, "rope_parameters", None) or {}).get("rope_theta", 10000.0)
+    for i, layer in enumerate(m.model.layers):
+        at = layer.self_attn
+        at.k_proj = DeployRuleLinear(at.k_proj, quantizers["model.layers.%d.self_attn.k_proj" % i], bits, True,
+                                     cfg.num_attention_heads, first_few_fp16, norm)
+        at.v_proj = DeployRuleLinear(at.v_proj, quantizers["model.layers.%d.self_attn.v_proj" % i], bits, False,
+                                     cfg.num_attention_heads, first_few_fp16, norm)
+        at.kvq_heads, at.kvq_hd, at.kvq_theta = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads, float(theta)
+        at.kvq_ff = max(first_few_fp16, 0)
+        at.kvq_nprompt = n_prompt
+        at.kvq_scores64 = bool(scores64)
+        at.forward = types.MethodType(_deploy_arith_forward, at)
+    return ppl_full_sequence(m, ids)
+
+
 @torch.no_grad()
 def ppl_full_sequence(model, ids):
     """next-token perplexity of one full-sequence forward (what llama_simquant.py's llama_eval computes per sample)"""
@@ -149,7 +225,12 @@ def _deploy_arith_forward(self, hidden_states, position_embeddings=None, attenti
         kh = self.k_proj.lin(hidden_states.half()).view(T, H, hd).transpose(0, 1)
         khr = kh * c16 + torch.cat((-kh[..., hd // 2:], kh[..., :hd // 2]), dim=-1) * s16
         kr[:, :ff] = khr[:, :ff].float()
-    scores = torch.matmul(qr.float(), kr.transpose(1, 2))                        # [H, T, T] fp32
+    if getattr(self, "kvq_scores64", False):
+        # the same scores summed in fp64 and rounded once: how much of a perplexity difference is nothing but the order of
+        # an fp32 summation in front of the half() of the next line (run() reports the spread)
+        scores = torch.matmul(qr.double(), kr.double().transpose(1, 2)).float()
+    else:
+        scores = torch.matmul(qr.float(), kr.transpose(1, 2))                    # [H, T, T] fp32
     w = (scores.half().float() * (1.0 / math.sqrt(hd))).half().float()
     mask = torch.ones(T, T, device=dev, dtype=torch.bool).tril()
     w = w.masked_fill(~mask, float("-inf"))
@@ -245,7 +326,17 @@ def run(layers=2, n_tokens=512, bits=4, first_few_fp16=0, vocab=32000, seed=0, n
     sim = sim_path_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm)
     simd = sim_deploy_arith_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm, n_prompt=n_prompt)
     ker = kernel_path_ppl(model, ids, quantizers, norm=norm, n_prompt=n_prompt)
-    return {"layers": layers, "tokens": n_tokens, "bits": bits, "first_few_fp16": first_few_fp16, "vocab": vocab,
+    try:
+        dep = deploy_rule_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm, n_prompt=n_prompt)
+        dep64 = deploy_rule_ppl(model, ids, quantizers, bits, first_few_fp16=ff, norm=norm, n_prompt=n_prompt, scores64=True)
+    except Exception as e:          # (never take the other comparators down with it)
+        dep = dep64 = float("nan")
+        if log:
+            log("deploy_rule_ppl failed: %s: %s" % (type(e).__name__, e))
+    return {"ppl_deploy_rule": dep, "rel_delta_vs_deploy_rule": (ker - dep) / dep,
+            # the comparator against ITSELF with the scores summed in another order (fp64): the noise floor of any comparison
+            # through the deployment path's half(score)
+            "ppl_deploy_rule_scores_fp64": dep64, "rel_summation_order_noise": (dep64 - dep) / dep,"layers": layers, "tokens": n_tokens, "bits": bits, "first_few_fp16": first_few_fp16, "vocab": vocab,
             "n_prompt": n_prompt, "norm": norm, "train_steps": train_steps, "ppl_fp16": base, "ppl_sim": sim, "ppl_sim_deploy_arith": simd,
             "ppl_kernel": ker, "delta": ker - sim, "rel_delta": (ker - sim) / sim,
             "rel_delta_vs_deploy_arith": (ker - simd) / simd}
