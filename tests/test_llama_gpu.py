@@ -30,22 +30,30 @@ NORTH_STAR = 0.01 / 5.47   # BASELINE.json north_star: wikitext-2 perplexity wit
 #   simd  the same fake-quantised K / V through the DEPLOYMENT path's arithmetic (fp16 score scaling and probabilities,
 #         ML:1972-1976; with a prompt: the prompt's rows over the unquantised K / V, ML:1861-1874) -- what the kernels
 #         have to reproduce;
-#   fp16  the unquantised model.
+#   fp16  the unquantised model;
+#   rule  (round 5) the DEPLOYMENT classes' own quantise -> dequantise of every token, restated by the oracle
+#         (oracle.glue: fp16-rounded thresholds, capped outliers, V thresholds from the 22nd largest / smallest value,
+#         strict clipping) + the deployment arithmetic in torch: the same numbers the kernels produce, summed in another
+#         order.  Two draws (profiles/r05_b_ppl_delta.jsonl): nuq4 -1.5e-4 / +4.8e-4, with prompt +4.9e-4 / -1.1e-4,
+#         nuq3 + 5 sinks +1.7e-3 / -1.5e-5, nuq2 + Q-Norm -8.9e-4 / +8.3e-5 -- both signs, no bias; the comparator's
+#         own perplexity moves by up to 2e-4 when ITS scores are summed in fp64 (the half() of every score turns a
+#         last-bit difference into a 2.8e-3 step of a probability).
 # Bars are FIXED (no data-dependent xfail): measured over three draws in round 4 (profiles/r04_ppl_delta.jsonl) --
 #   nuq4 (+ prompt): |kernel - simd| <= 6.2e-4, |kernel - sim| <= 1.7e-3 (prompt: 4.3e-3, sim does not model the prefill);
 #   nuq3 + 5 sinks:  <= 2.3e-3 / 5.1e-3 (the reference's two paths pick V outliers differently -- quantile vs top-21 --
 #                    which moves a token's scale, and at 3 bit that shows);   nuq2 + Q-Norm: <= 3.7e-4 / 5.2e-3.
 PPL_CASES = [
-    # kw, bar vs simd, bar vs sim
-    (dict(bits=4), NORTH_STAR, 5e-3),
-    (dict(bits=4, n_prompt=1024), NORTH_STAR, 1e-2),
-    (dict(bits=3, first_few_fp16=5), 5e-3, 1e-2),
-    (dict(bits=2, norm=True), NORTH_STAR, 1e-2),
+    # kw, bar vs simd, bar vs sim, bar vs rule
+    (dict(bits=4), NORTH_STAR, 5e-3, NORTH_STAR),
+    (dict(bits=4, n_prompt=1024), NORTH_STAR, 1e-2, NORTH_STAR),
+    (dict(bits=3, first_few_fp16=5), 5e-3, 1e-2, 3e-3),
+    (dict(bits=2, norm=True), NORTH_STAR, 1e-2, NORTH_STAR),
 ]
 
 
-@pytest.mark.parametrize("kw,bar_simd,bar_sim", PPL_CASES, ids=["nuq4", "nuq4-prompt1024", "nuq3-sink5", "nuq2-qnorm"])
-def test_ppl_kernel_path_vs_reference_paths(gpu, kw, bar_simd, bar_sim):
+@pytest.mark.parametrize("kw,bar_simd,bar_sim,bar_rule", PPL_CASES,
+                         ids=["nuq4", "nuq4-prompt1024", "nuq3-sink5", "nuq2-qnorm"])
+def test_ppl_kernel_path_vs_reference_paths(gpu, kw, bar_simd, bar_sim, bar_rule):
     from tests import ppl_harness
     r = ppl_harness.run(layers=2, n_tokens=2048, vocab=4096, train_steps=600, **kw)
     print(r)
@@ -53,6 +61,7 @@ def test_ppl_kernel_path_vs_reference_paths(gpu, kw, bar_simd, bar_sim):
     assert r["ppl_fp16"] < 20, "the stand-in model did not train (ideal perplexity of the stream: 5.48)"
     assert abs(r["rel_delta_vs_deploy_arith"]) < bar_simd, r
     assert abs(r["rel_delta"]) < bar_sim, r
+    assert abs(r["rel_delta_vs_deploy_rule"]) < bar_rule, r
     # quantisation is not a no-op: the kernel path is NOT the fp16 model (nuq4 measured >= 1.2e-3 away, coarser ones more)
     assert abs(r["ppl_kernel"] - r["ppl_fp16"]) / r["ppl_fp16"] > 1e-4, r
 

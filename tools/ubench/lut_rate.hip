@@ -23,6 +23,11 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
   f32x2 q0, q1, q2, q3, q4, q5, q6, q7;
   const unsigned we = (w << 2) & 0x3C3C3C3Cu, wo = (w >> 2) & 0x3C3C3C3Cu;
   const unsigned ke = (w << 3) & 0x78787878u, ko = (w >> 1) & 0x78787878u;
+  // shader clock of the run: s_memtime (shader cycles) against s_memrealtime (100 MHz) around the loop, wave 0 of block 0
+  unsigned long long c0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+  }
   for (int it = 0; it < iters; it++) {
     if (MODE == 0 || MODE == 2) {   // extraction (V kernel form: bytes of two pre-masked words)
       asm volatile("v_and_b32 %0, 0xff, %8\n v_and_b32 %1, 0xff, %9\n v_bfe_u32 %2, %8, 8, 8\n v_bfe_u32 %3, %9, 8, 8\n"
@@ -105,6 +110,14 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
     }
   }
   float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (p0 + p1 + p2 + p3).x + (p0 + p1 + p2 + p3).y;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    unsigned long long c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    if (threadIdx.x == 0) {
+      reinterpret_cast<unsigned long long *>(out)[1] = c1 - c0;
+      reinterpret_cast<unsigned long long *>(out)[2] = r1 - r0;
+    }
+  }
   if (s == 12345.678f) out[0] = s;
 }
 template <int MODE>
@@ -119,8 +132,11 @@ static void run(const char *name, float *d, int blocks) {
     hipEventElapsedTime(&ms, e0, e1);
   }
   double steps_per_simd = (blocks / 256.0) * 2.0 * iters * 8.0;   // waves per SIMD x code steps per wave
-  printf("%-44s %d waves/SIMD: %8.3f ms -> %6.2f ns per code-step per SIMD (%.2f per wave)\n", name, blocks / 128, ms,
-         ms * 1e6 / steps_per_simd, ms * 1e6 / (iters * 8.0));
+  unsigned long long h[3];
+  hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  const double mhz = h[2] ? (double)h[1] / (double)h[2] * 100.0 : 0.0;
+  printf("%-44s %d waves/SIMD: %8.3f ms -> %6.2f ns per code-step per SIMD (%.2f per wave) = %5.2f shader cycles per code-step per SIMD at %4.0f MHz\n",
+         name, blocks / 128, ms, ms * 1e6 / steps_per_simd, ms * 1e6 / (iters * 8.0), ms * 1e6 / steps_per_simd * mhz * 1e-3, mhz);
 }
 #define RUN(M, NAME) run<M>(NAME, d, 512); run<M>(NAME, d, 256);
 int main() {
