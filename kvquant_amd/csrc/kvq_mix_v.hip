@@ -1001,7 +1001,17 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   Plan pl;
   pl.n_units = H * Cfg::UPH;
   pl.groups = (pl.n_units + Cfg::UW - 1) / Cfg::UW;
-  int64_t want = KVQ_V_WGS / pl.groups;   // KVQ_V_WGS / 256 workgroups of 512 lanes per CU
+  static const int wgs_rt = [] {
+    const char *e = getenv("KVQ_V_WGS_RT");          // (A/B runs)
+    return e ? atoi(e) : 0;
+  }();
+  // KVQ_V_WGS / 256 workgroups of 512 lanes per CU.  One unit group (3 / 2 bit: every workgroup covers all heads, 16-token
+  // chunks) up to 48K tokens: one workgroup per CU -- its fixed work (the partials of 32 heads, the outlier phase, a 16 KB
+  // slab) is then spread over 8 chunks instead of 4 (32K nuq3 + 5 sinks 3.24 -> 3.18 ms / step, nuq2 2.82 -> 2.73; at 128K
+  // 512 workgroups win by 11 us per launch (64K: by 3.5; 48K: a tie; 16K: 256 win by 5), and two unit groups (4 bit) want 512 at every length:
+  // profiles/r05_pv_plan.txt)
+  const int wgs = wgs_rt > 0 ? wgs_rt : ((pl.groups == 1 && L <= 49152) ? KVQ_V_WGS / 2 : KVQ_V_WGS);
+  int64_t want = wgs / pl.groups;
   if (want < 1) want = 1;
   int64_t tr = (L + want - 1) / want;
   tr = (tr + Cfg::CT - 1) / Cfg::CT * Cfg::CT;
@@ -1024,6 +1034,19 @@ static bool split_enabled() {
   return on;
 }   // up to this many score tiles (256 tokens each): the p.V workgroups merge the softmax partials themselves
 
+// Up to how many score tiles the p.V workgroups merge the softmax partials themselves.  With sink tokens whose values are
+// added here (v_sink) the merge kernel runs at every length: in the in-kernel variant workgroup 0 alone writes the sink
+// probabilities and the sink tokens' 4096 outputs before its own range, and the launch waits for it (32K nuq4 + 5 sinks:
+// p.V 51 us against 37 without sinks).  KVQ_V_MERGE_PARTS_RT overrides the threshold (A/B runs).
+static int merge_in_kernel_parts(bool sink_outputs) {
+  static const int rt = [] {
+    const char *e = getenv("KVQ_V_MERGE_PARTS_RT");
+    return e ? atoi(e) : -1;
+  }();
+  if (rt >= 0) return rt;
+  return sink_outputs ? 0 : kMergeInKernelParts;
+}
+
 template <int BITS>
 static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, const FusedSoftmax *fs = nullptr) {
   using Cfg = VCfg<BITS>;
@@ -1036,8 +1059,10 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   // bound by the bytes every group re-reads (128K nuq4: see DESIGN.md); short ones keep the per-group rows (the groups
   // merge the softmax partials of their own heads only, and the extra slabs would double the reduce's work)
   const int C_all = a.H * kHeadDim;
+  const bool merge_first = fs && fs->n_parts > merge_in_kernel_parts(fs->n_sink > 0 && fs->v_sink != nullptr);
   a.split = (a.idx != nullptr && a.q_len == 1 && pl.groups >= 2 && C_all <= (Cfg::SMEM_B - Cfg::SP_P_B) / 8 - 64 &&
-             a.H <= Cfg::SP_P_B / (4 * 65) && (fs ? fs->n_parts > kMergeInKernelParts : a.L >= 65536) && split_enabled()) ? 1 : 0;
+             a.H <= Cfg::SP_P_B / (4 * 65) && (fs ? (merge_first && fs->n_parts > kMergeInKernelParts) : a.L >= 65536) &&
+             split_enabled()) ? 1 : 0;
   const int n_slabs = a.split ? pl.n_ranges * pl.groups : pl.n_ranges;
   if (fs) {
     a.scores = fs->scores;
@@ -1051,7 +1076,7 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
     a.sink_out = mul;
     if (fs->v_sink != nullptr) accumulate = 1;     // the reduce adds the slabs onto the sink tokens' output
     a.mz = nullptr;
-    if (fs->n_parts > kMergeInKernelParts) {
+    if (merge_first) {
       float *mz = a.partial + (size_t)pl.n_ranges * (a.q_len == 1 ? pl.groups : a.q_len) * a.H * kHeadDim;   // (tail of the workspace)
       softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz,
                                                 fs->v_sink, mul);

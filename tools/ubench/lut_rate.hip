@@ -14,7 +14,8 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
   for (int i = threadIdx.x; i < 4096; i += 512) tab[i] = (float)i * 0.001f;
   __syncthreads();
   float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
-  f32x2 p0 = {0, 0}, p1 = p0, p2 = p0, p3 = p0;
+  f32x2 p0 = {0, 0}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
+  float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
   f32x2 cs = {0.5f, 0.25f};
   unsigned w = (threadIdx.x * 2654435761u) ^ seed;
   const float pt = 0.37f;
@@ -108,8 +109,75 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
       asm volatile("v_dot2_f32_f16 %0, %4, %8, %0\n v_dot2_f32_f16 %1, %5, %8, %1\n v_dot2_f32_f16 %2, %6, %8, %2\n v_dot2_f32_f16 %3, %7, %8, %3\n"
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(pt));
     }
+    // ---- 3-bit V forms, 16 codes (one token of a lane's half) per iteration
+    // MODE 10: as kvq_mix_lut.h today -- streams 2, tri_prep 2 x 4, 16 field cuts, 16 ds_read_b32 (32-byte rows), 16 v_fmac
+    if (MODE == 10) {
+      unsigned s1, s2, e1, o1, e2, o2, x0, x1, x2, x3, x4, x5, x6, x7;
+      float y0, y1, y2, y3, y4, y5, y6, y7;
+      asm volatile("v_mov_b32 %0, %2\n v_alignbit_b32 %1, %3, %2, 30" : "=&v"(s1), "=&v"(s2) : "v"(we), "v"(wo));
+      asm volatile("v_and_b32 %0, %3, %2\n v_lshrrev_b32 %1, 1, %2\n v_lshl_or_b32 %0, %0, 2, %5\n v_and_or_b32 %1, %1, %4, %5"
+                   : "=&v"(e1), "=&v"(o1) : "v"(s1), "s"(0x071C71C7u), "s"(0x1C71C71Cu), "v"(0u));
+      asm volatile("v_and_b32 %0, %3, %2\n v_lshrrev_b32 %1, 1, %2\n v_lshl_or_b32 %0, %0, 2, %5\n v_and_or_b32 %1, %1, %4, %5"
+                   : "=&v"(e2), "=&v"(o2) : "v"(s2), "s"(0x071C71C7u), "s"(0x1C71C71Cu), "v"(0u));
+      asm volatile("v_and_b32 %0, 63, %8\n v_and_b32 %1, 63, %9\n v_bfe_u32 %2, %8, 6, 6\n v_bfe_u32 %3, %9, 6, 6\n"
+                   "v_bfe_u32 %4, %8, 12, 6\n v_bfe_u32 %5, %9, 12, 6\n v_bfe_u32 %6, %8, 18, 6\n v_bfe_u32 %7, %9, 18, 6"
+                   : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6), "=&v"(u7) : "v"(e1), "v"(o1));
+      asm volatile("ds_read_b32 %0, %8 offset:0\n ds_read_b32 %1, %9 offset:0\n ds_read_b32 %2, %10 offset:0\n ds_read_b32 %3, %11 offset:0\n"
+                   "ds_read_b32 %4, %12 offset:0\n ds_read_b32 %5, %13 offset:0\n ds_read_b32 %6, %14 offset:0\n ds_read_b32 %7, %15 offset:0\n"
+                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                   : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(u4), "v"(u5), "v"(u6), "v"(u7) : "memory");
+      asm volatile("v_bfe_u32 %0, %8, 24, 6\n v_bfe_u32 %1, %9, 24, 6\n v_and_b32 %2, 63, %10\n v_and_b32 %3, 63, %11\n"
+                   "v_bfe_u32 %4, %10, 6, 6\n v_bfe_u32 %5, %11, 6, 6\n v_bfe_u32 %6, %10, 12, 6\n v_bfe_u32 %7, %11, 12, 6"
+                   : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7) : "v"(e1), "v"(o1), "v"(e2), "v"(o2));
+      asm volatile("ds_read_b32 %0, %8 offset:64\n ds_read_b32 %1, %9 offset:64\n ds_read_b32 %2, %10 offset:64\n ds_read_b32 %3, %11 offset:64\n"
+                   "ds_read_b32 %4, %12 offset:64\n ds_read_b32 %5, %13 offset:64\n ds_read_b32 %6, %14 offset:64\n ds_read_b32 %7, %15 offset:64\n"
+                   : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(y4), "=&v"(y5), "=&v"(y6), "=&v"(y7)
+                   : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(8)\n"
+                   "v_fmac_f32 %0, %8, %16\n v_fmac_f32 %1, %9, %16\n v_fmac_f32 %2, %10, %16\n v_fmac_f32 %3, %11, %16\n"
+                   "v_fmac_f32 %4, %12, %16\n v_fmac_f32 %5, %13, %16\n v_fmac_f32 %6, %14, %16\n v_fmac_f32 %7, %15, %16\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                   : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(pt));
+      asm volatile("s_waitcnt lgkmcnt(0)\n"
+                   "v_fmac_f32 %0, %8, %16\n v_fmac_f32 %1, %9, %16\n v_fmac_f32 %2, %10, %16\n v_fmac_f32 %3, %11, %16\n"
+                   "v_fmac_f32 %4, %12, %16\n v_fmac_f32 %5, %13, %16\n v_fmac_f32 %6, %14, %16\n v_fmac_f32 %7, %15, %16\n"
+                   : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)
+                   : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(y4), "v"(y5), "v"(y6), "v"(y7), "v"(pt));
+    }
+    // MODE 11 / 12: PAIR rows -- a token's row is 64 float2 entries (value of code a, value of code b), 512 bytes; per 16
+    // codes: streams 2, 5 shift + and_or preps, 6 cuts, 8 ds_read_b64, 8 v_pk_fma_f32.  12: the look-ups alone.
+    if (MODE == 11 || MODE == 12) {
+      unsigned s1, s2, A, B, C, A2, B2;
+      asm volatile("v_mov_b32 %0, %2\n v_alignbit_b32 %1, %3, %2, 30" : "=&v"(s1), "=&v"(s2) : "v"(we), "v"(wo));
+      if (MODE == 11) {
+        asm volatile("v_lshlrev_b32 %0, 3, %5\n v_lshrrev_b32 %1, 3, %5\n v_lshrrev_b32 %2, 21, %5\n v_lshlrev_b32 %3, 3, %6\n v_lshrrev_b32 %4, 3, %6\n"
+                     "v_and_or_b32 %0, %0, %7, %9\n v_and_or_b32 %1, %1, %7, %9\n v_and_or_b32 %2, %2, %8, %10\n v_and_or_b32 %3, %3, %7, %9\n v_and_or_b32 %4, %4, %8, %10\n"
+                     : "=&v"(A), "=&v"(B), "=&v"(C), "=&v"(A2), "=&v"(B2)
+                     : "v"(s1), "v"(s2), "s"(0x001F81F8u), "s"(0x1F8u), "v"(0x00200200u & (w >> 3)), "v"(0x200u & (w >> 3)));
+        asm volatile("v_and_b32 %0, 0xfff, %6\n v_lshrrev_b32 %1, 12, %6\n v_and_b32 %2, 0xfff, %7\n v_lshrrev_b32 %3, 12, %7\n"
+                     "v_and_b32 %4, 0xfff, %8\n v_lshrrev_b32 %5, 12, %8\n"
+                     : "=&v"(u0), "=&v"(u2), "=&v"(u1), "=&v"(u3), "=&v"(u5), "=&v"(u7) : "v"(A), "v"(B), "v"(A2));
+        u4 = C; u6 = B2;
+      } else {
+        u0 = ke & 0x3f8; u1 = ko & 0x3f8; u2 = (ke >> 8) & 0x3f8; u3 = (ko >> 8) & 0x3f8; u4 = (ke >> 16) & 0x3f8; u5 = (ko >> 16) & 0x3f8;
+        u6 = (ke >> 20) & 0x3f8; u7 = (ko >> 20) & 0x3f8;
+      }
+      asm volatile("ds_read_b64 %0, %8 offset:0\n ds_read_b64 %1, %9 offset:0\n ds_read_b64 %2, %10 offset:0\n ds_read_b64 %3, %11 offset:0\n"
+                   "ds_read_b64 %4, %12 offset:0\n ds_read_b64 %5, %13 offset:0\n ds_read_b64 %6, %14 offset:0\n ds_read_b64 %7, %15 offset:0\n"
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+                   : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(u4), "v"(u5), "v"(u6), "v"(u7) : "memory");
+      if (MODE == 11) {
+        asm volatile("v_pk_fma_f32 %0, %8, %16, %0\n v_pk_fma_f32 %1, %9, %16, %1\n v_pk_fma_f32 %2, %10, %16, %2\n v_pk_fma_f32 %3, %11, %16, %3\n"
+                     "v_pk_fma_f32 %4, %12, %16, %4\n v_pk_fma_f32 %5, %13, %16, %5\n v_pk_fma_f32 %6, %14, %16, %6\n v_pk_fma_f32 %7, %15, %16, %7\n"
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                     : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(cs));
+      } else {
+        p0 += q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;
+      }
+    }
   }
-  float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (p0 + p1 + p2 + p3).x + (p0 + p1 + p2 + p3).y;
+  float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + (p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7).x + (p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7).y;
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     unsigned long long c1, r1;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
@@ -120,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned seed
   }
   if (s == 12345.678f) out[0] = s;
 }
-template <int MODE>
+template <int MODE, int CODES = 8>
 static void run(const char *name, float *d, int blocks) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int iters = 20000;
@@ -131,12 +199,12 @@ static void run(const char *name, float *d, int blocks) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
-  double steps_per_simd = (blocks / 256.0) * 2.0 * iters * 8.0;   // waves per SIMD x code steps per wave
+  double steps_per_simd = (blocks / 256.0) * 2.0 * iters * (double)CODES;   // waves per SIMD x code steps per wave
   unsigned long long h[3];
   hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
   const double mhz = h[2] ? (double)h[1] / (double)h[2] * 100.0 : 0.0;
   printf("%-44s %d waves/SIMD: %8.3f ms -> %6.2f ns per code-step per SIMD (%.2f per wave) = %5.2f shader cycles per code-step per SIMD at %4.0f MHz\n",
-         name, blocks / 128, ms, ms * 1e6 / steps_per_simd, ms * 1e6 / (iters * 8.0), ms * 1e6 / steps_per_simd * mhz * 1e-3, mhz);
+         name, blocks / 128, ms, ms * 1e6 / steps_per_simd, ms * 1e6 / (iters * (double)CODES), ms * 1e6 / steps_per_simd * mhz * 1e-3, mhz);
 }
 #define RUN(M, NAME) run<M>(NAME, d, 512); run<M>(NAME, d, 256);
 int main() {
@@ -145,6 +213,10 @@ int main() {
   RUN(3, "K form: bfe/and/lshr + v_pk_fma (no LDS)") RUN(4, "K form: 8 x ds_read_b64 only") RUN(5, "K form: extraction + ds_read_b64 + v_pk_fma")
   RUN(6, "K16 form: bfe/and/lshr + v_dot2_f32_f16 (no LDS)") RUN(7, "K16 form: 8 x ds_read_b32 (128 B apart) only") RUN(8, "K16 form: extraction + ds_read_b32 + v_dot2")
   RUN(9, "K16 3-bit pair form: 4 cuts + 4 ds_read_b32 + 4 v_dot2 per 8 codes")
+#define RUN16(M, NAME) run<M, 16>(NAME, d, 512); run<M, 16>(NAME, d, 256);
+  RUN16(10, "V 3-bit form today: 26 int ops + 16 ds_read_b32 + 16 v_fmac per 16 codes")
+  RUN16(11, "V 3-bit PAIR rows: 18 int ops + 8 ds_read_b64 + 8 v_pk_fma per 16 codes")
+  RUN16(12, "V 3-bit PAIR rows: 8 x ds_read_b64 in 512-byte rows only")
   printf("budget of the kernels at 128K: q.K^T 87 us and p.V 82 us over 8192 code-steps per SIMD = 10.6 / 10.0 ns per code-step\n");
   return 0;
 }
