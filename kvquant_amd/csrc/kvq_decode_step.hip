@@ -139,10 +139,11 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
   const int n_sink = sinks ? sinks->n_sink : 0;
   const float inv = 1.0f / sqrtf((float)hd);
   const float *ktab = ly->klut_score ? ly->klut_score : ly->klut;
-  int rc = kvq_decode_prologue(bits, ly->kmat, ly->klut, ly->klut_off, k, ly->klo, ly->khi, ly->koutliers, ly->kidx, kcol,
-                               ly->vmat, ly->vlut_rows, ly->vlut_sorted, v, ly->voutliers, ly->vidx, vcol, q,
-                               acts_are_half, ly->thr_k, H, hd, ly->max_len, ly->koutliers_t, ly->kidx_t, ly->klut_ends,
-                               ly->klut_score, ly->vnorm, sinks, ws, p.score_ws, stream);
+  int rc = decode_prologue(bits, ly->kmat, ly->klut, ly->klut_off, k, ly->klo, ly->khi, ly->koutliers, ly->kidx, kcol,
+                           ly->vmat, ly->vlut_rows, ly->vlut_sorted, v, ly->voutliers, ly->vidx, vcol, q,
+                           acts_are_half, ly->thr_k, H, hd, ly->max_len, ly->koutliers_t, ly->kidx_t, ly->klut_ends,
+                           ly->klut_score, ly->vnorm, sinks, ws, p.score_ws,
+                           (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) != 0, stream);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   struct Clear { ~Clear() { step_events = nullptr; } } clear_events_on_exit;

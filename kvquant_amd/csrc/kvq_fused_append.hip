@@ -524,12 +524,20 @@ __global__ __launch_bounds__(kSelThreads) void decode_prologue_kernel(PrologueAr
     const int h = (int)blockIdx.x - 2;
     quantize_head<BITS>(P.k, h);
     lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.pair_tab, P.H, h, 0);
-    if (P.k_sink != nullptr && (int)threadIdx.x < P.n_sink) {
-      const int i = threadIdx.x;
-      float acc = 0.f;
-      for (int c = 0; c < kHeadDim; c++)
-        acc = fmaf(ld_act(P.q, h * kHeadDim + c, P.q_is_half), __half2float(P.k_sink[((int64_t)h * kHeadDim + c) * P.n_sink + i]), acc);
-      P.sink_scores[h * P.n_sink + i] = __float2half_rn(scaled(acc, P.sink_inv));
+    if (P.k_sink != nullptr) {
+      // scores of the fp16 sink tokens: one wave per sink token, two channels per lane (one thread per token walked the
+      // 128 channels alone -- 128 dependent loads, which made these workgroups the prologue's critical path: 19.4 us
+      // against 12.2 without sink tokens)
+      static_assert(kHeadDim == 128, "two channels per lane");
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+      const float q0 = ld_act(P.q, h * kHeadDim + lane, P.q_is_half), q1 = ld_act(P.q, h * kHeadDim + lane + 64, P.q_is_half);
+      for (int i = wave; i < P.n_sink; i += nw) {
+        float acc = q0 * __half2float(P.k_sink[((int64_t)h * kHeadDim + lane) * P.n_sink + i]);
+        acc = fmaf(q1, __half2float(P.k_sink[((int64_t)h * kHeadDim + lane + 64) * P.n_sink + i]), acc);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) P.sink_scores[h * P.n_sink + i] = __float2half_rn(scaled(acc, P.sink_inv));
+      }
     }
   }
 }
@@ -692,14 +700,19 @@ int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_s
                                         max_len, col0, norm), H, hd, S, (hipStream_t)stream);
 }
 
-int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klut_off, const void *k,
-                        const float *lo, const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
-                        int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
-                        float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
-                        int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
-                        const float *klut_ends, const float *klut_score, const kvq_vopts *vnorm,
-                        const kvq_sinks *sinks, void *score_workspace, size_t score_workspace_bytes,
-                        void *stream) {
+}  // extern "C"
+
+namespace kvq {
+// kvq_decode_prologue with the choice of score images: `pair_images` = also the 3-bit fp16 pair-sum image (KTabPair3;
+// 4096 gathered entries per head -- only the layers that score with it pay for it)
+int decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klut_off, const void *k,
+                    const float *lo, const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
+                    int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
+                    float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
+                    int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
+                    const float *klut_ends, const float *klut_score, const kvq_vopts *vnorm,
+                    const kvq_sinks *sinks, void *score_workspace, size_t score_workspace_bytes,
+                    bool pair_images, void *stream) {
   if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
   if (sinks != nullptr && sinks->n_sink > 0 && (!sinks->k_sink || !sinks->sink_scores || sinks->n_sink > 1024))
     return KVQ_EINVAL;
@@ -723,7 +736,7 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
   P.tab = reinterpret_cast<unsigned char *>(score_workspace);
   const size_t tabb = bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
   P.q32 = reinterpret_cast<float *>(P.tab + (size_t)H * tabb);
-  P.pair_tab = bits == 3 ? P.tab + ktab_pair_offset<3>(1, H) : nullptr;
+  P.pair_tab = (bits == 3 && pair_images) ? P.tab + ktab_pair_offset<3>(1, H) : nullptr;
   P.H = H;
   P.k_sink = nullptr;
   P.sink_scores = nullptr;
@@ -750,6 +763,23 @@ int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float 
     default: decode_prologue_kernel<2><<<grid, block, 0, st>>>(P); break;
   }
   return check_launch();
+}
+}  // namespace kvq
+
+extern "C" {
+
+// (the public entry builds every image kvq_score_k_prepared* may be asked to read)
+int kvq_decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klut_off, const void *k,
+                        const float *lo, const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
+                        int32_t *vmat, float *vlut_rows, const float *vlut_sorted, const void *v,
+                        float *voutliers, int32_t *vidx, int64_t vcol, const void *q, int acts_are_half,
+                        int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
+                        const float *klut_ends, const float *klut_score, const kvq_vopts *vnorm,
+                        const kvq_sinks *sinks, void *score_workspace, size_t score_workspace_bytes,
+                        void *stream) {
+  return kvq::decode_prologue(bits, kmat, klut, klut_off, k, lo, hi, koutliers, kidx, kcol, vmat, vlut_rows, vlut_sorted, v,
+                              voutliers, vidx, vcol, q, acts_are_half, thr_k, H, hd, max_len, koutliers_t, kidx_t, klut_ends,
+                              klut_score, vnorm, sinks, score_workspace, score_workspace_bytes, true, stream);
 }
 
 /* K append | V append of one token as ONE launch (the two selection workgroups of kvq_decode_prologue without the table
