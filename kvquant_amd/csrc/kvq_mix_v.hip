@@ -1024,7 +1024,7 @@ static Plan plan_mix(int q_len, int H, int64_t L) {
   return pl;
 }
 
-constexpr int kMergeInKernelParts = KVQ_V_MERGE_PARTS;
+constexpr int kMergeInKernelParts = KVQ_V_MERGE_PARTS;   // score tiles (256 tokens each)
 // KVQ_V_SPLIT=0: the per-group rows phase at every length (A/B runs)
 static bool split_enabled() {
   static const bool on = [] {
@@ -1032,7 +1032,7 @@ static bool split_enabled() {
     return !(e && e[0] == '0');
   }();
   return on;
-}   // up to this many score tiles (256 tokens each): the p.V workgroups merge the softmax partials themselves
+}
 
 // Up to how many score tiles the p.V workgroups merge the softmax partials themselves.  With sink tokens whose values are
 // added here (v_sink) the merge kernel runs at every length: in the in-kernel variant workgroup 0 alone writes the sink
