@@ -1,4 +1,4 @@
-// Prefill pack, tiled: FOUR prompt tokens per workgroup, the channel-major prompt [C][S] read ONCE with 16-byte loads.
+// Prefill pack, tiled: kTT prompt tokens per workgroup, the channel-major prompt [C][S] read ONCE with 8- or 16-byte loads.
 // Included by kvq_fused_append.hip (uses AppendArgs, fkey, wave_incl_scan, nearest_code, pack32).
 //
 // The reference runs torch.topk over [S, C] plus ~10 elementwise launches around its pack kernel
@@ -16,19 +16,33 @@
 //     row (+ K mirror); K residuals re-read the 42 selected values from the prompt (L2-hot);
 //   phase 3: codes -> packed words, the four tokens of a row next to each other (16-byte pieces).
 // Results are bit-identical to the per-token kernel (tests/test_atsize_gpu.py, test_decode_kv_gpu.py).
+//
+// Tokens per workgroup (round 5): the kernel is a chain of barrier-separated steps (four radix passes, scans, compaction),
+// i.e. bound by latencies that only ANOTHER workgroup on the CU can fill.  Four tokens need 150 KB of LDS -- one workgroup per
+// CU; TWO tokens with one histogram copy need 50 KB -- three workgroups of 512 lanes per CU: 8192 tokens nuq4 K 274 -> 211 us,
+// V 246 -> 180 (two tokens with two copies, two workgroups per CU: 244 / 209; profiles/r05_pack_tokens.txt).  The price is the
+// K codebook row of a channel read per two tokens instead of four (L2).
 #pragma once
 
 namespace kvq {
 
-constexpr int kTT = 4;          // tokens per workgroup
+#ifndef KVQ_PACK_TT
+#define KVQ_PACK_TT 2
+#endif
+#ifndef KVQ_PACK_THC
+#define KVQ_PACK_THC 1
+#endif
+constexpr int kTT = KVQ_PACK_TT;   // tokens per workgroup (4 or 2)
+static_assert(kTT == 4 || kTT == 2, "the prompt is read as one 16- or 8-byte piece per channel");
 constexpr int kTG = 256;        // lanes per token group
 constexpr int kTNT = kTT * kTG;
 constexpr int kTE = 16;         // channels per lane in phase 2: C <= 4096
 constexpr int kTC = kTG * kTE;  // 4096
 
-constexpr int kTHC = 4;         // copies of a selection histogram, lanes spread over them: same-address LDS atomics serialise
-                                // (the first pass puts a token's 4096 keys into ~10 bins; round 4 measured 46 % / 54 % of the
-                                // kernel's LDS-active cycles as bank conflicts with ONE copy; the LDS is there: 150 of 160 KB)
+constexpr int kTHC = KVQ_PACK_THC;   // copies of a selection histogram, lanes spread over them (same-address LDS atomics
+                                     // serialise: the first pass puts a token's 4096 keys into ~10 bins).  Four copies
+                                     // changed nothing measurable at four tokens per workgroup; one copy is what lets three
+                                     // workgroups share a CU at two tokens
 struct TiledSel {
   uint32_t hist[2][2][kTHC][256];     // [pass parity][side][copy][digit]
   uint32_t prefix[2], krem[2];
@@ -38,7 +52,7 @@ struct TiledSel {
 
 struct TiledShared {
   float ss[kTT][kTC + kTC / 32];          // K: rescaled values, V: values; channel c at c + c/32
-  unsigned char cb[kTT][kTC + 16];        // codes (+16: the four tokens of a 32-channel group in different banks for the pack's reads)
+  unsigned char cb[kTT][kTC + 16];        // codes (+16: the tokens of a 32-channel group in different banks for the pack's reads)
   TiledSel sel[kTT];
   int any_cut;
 };
@@ -133,8 +147,8 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
   const int tid = threadIdx.x;
   const int C = A.C, thr_k = A.thr_k;
   const int64_t max_len = A.max_len;
-  // token quads are handed to the XCDs in contiguous ranges (workgroup b runs on XCD b % 8): the eight quads that share
-  // each 128-byte line of the channel-major prompt then go through one L2, dispatched back to back
+  // token groups are handed to the XCDs in contiguous ranges (workgroup b runs on XCD b % 8): the 32 / kTT groups that
+  // share each 128-byte line of the channel-major prompt then go through one L2, dispatched back to back
   const int64_t nb = gridDim.x, nq = (S + kTT - 1) / kTT;
   const int64_t per_xcd = (nb + 7) / 8;
   int64_t quad = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -145,10 +159,17 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
 
   // ---- phase 1: lane = channel -----------------------------------------------------------------------------------
   for (int c = tid; c < kTC; c += kTNT) {
-    float xv[kTT] = {0.f, 0.f, 0.f, 0.f};
+    float xv[kTT];
+#pragma unroll
+    for (int t = 0; t < kTT; t++) xv[t] = 0.f;
     if (c < C) {
-      const float4 v4 = *reinterpret_cast<const float4 *>(xq + (int64_t)c * S);   // (S % 4 == 0, 16-byte aligned base)
-      xv[0] = v4.x; xv[1] = v4.y; xv[2] = v4.z; xv[3] = v4.w;
+      if constexpr (kTT == 4) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(xq + (int64_t)c * S);   // (S % 4 == 0, 16-byte aligned base)
+        xv[0] = v4.x; xv[1] = v4.y; xv[2] = v4.z; xv[3] = v4.w;
+      } else {
+        const float2 v2 = *reinterpret_cast<const float2 *>(xq + (int64_t)c * S);
+        xv[0] = v2.x; xv[1] = v2.y;
+      }
     }
     const int cp = c + (c >> 5);
     if constexpr (!IS_V) {
