@@ -20,8 +20,9 @@
 // Tokens per workgroup (round 5): the kernel is a chain of barrier-separated steps (four radix passes, scans, compaction),
 // i.e. bound by latencies that only ANOTHER workgroup on the CU can fill.  Four tokens need 150 KB of LDS -- one workgroup per
 // CU; TWO tokens with one histogram copy need 50 KB -- three workgroups of 512 lanes per CU: 8192 tokens nuq4 K 274 -> 211 us,
-// V 246 -> 180 (two tokens with two copies, two workgroups per CU: 244 / 209; profiles/r05_pack_tokens.txt).  The price is the
-// K codebook row of a channel read per two tokens instead of four (L2).
+// V 246 -> 180 (two tokens with two copies, two workgroups per CU: 244 / 209; ONE token, 4-byte loads, 4 - 5 workgroups per CU:
+// 305 / 255 -- profiles/r05_pack_tokens.txt).  The price is the K codebook row of a channel read per two tokens instead of
+// four (L2).
 #pragma once
 
 namespace kvq {
@@ -33,7 +34,7 @@ namespace kvq {
 #define KVQ_PACK_THC 1
 #endif
 constexpr int kTT = KVQ_PACK_TT;   // tokens per workgroup (4 or 2)
-static_assert(kTT == 4 || kTT == 2, "the prompt is read as one 16- or 8-byte piece per channel");
+static_assert(kTT == 4 || kTT == 2 || kTT == 1, "the prompt is read as one 16-, 8- or 4-byte piece per channel");
 constexpr int kTG = 256;        // lanes per token group
 constexpr int kTNT = kTT * kTG;
 constexpr int kTE = 16;         // channels per lane in phase 2: C <= 4096
@@ -166,9 +167,11 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
       if constexpr (kTT == 4) {
         const float4 v4 = *reinterpret_cast<const float4 *>(xq + (int64_t)c * S);   // (S % 4 == 0, 16-byte aligned base)
         xv[0] = v4.x; xv[1] = v4.y; xv[2] = v4.z; xv[3] = v4.w;
-      } else {
+      } else if constexpr (kTT == 2) {
         const float2 v2 = *reinterpret_cast<const float2 *>(xq + (int64_t)c * S);
         xv[0] = v2.x; xv[1] = v2.y;
+      } else {
+        xv[0] = xq[(int64_t)c * S];
       }
     }
     const int cp = c + (c >> 5);
