@@ -49,3 +49,22 @@ def test_bench_head_sharded_single_rank():
     d = _run("--shard", "heads", "--ctx", "2048", "--layers", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
              "--no-fp16-baseline")
     assert d["scaling"] == "strong" and d["value"] > 0 and "head-sharded" in d["config"]["parallelism"]
+
+
+def test_bench_prefill_line_contract():
+    """BASELINE config 4 as a bench line (`--prefill`): pack K / V and the MFMA attention of an 8192-token prompt, with the
+    roofline arithmetic of the pack kernel written out."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run("--prefill", "--bits", "3")
+    for key in ("metric", "value", "unit", "n_gpus", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config",
+                "roofline", "kernels"):
+        assert key in d, key
+    assert d["config"]["S"] == 8192 and d["config"]["bits"] == 3 and d["value"] > 0 and d["vs_baseline"] is None
+    k = d["kernels"]
+    for key in ("pack_k_us", "pack_v_us", "prefill_attention_us", "prefill_attention_TFLOPs"):
+        assert k[key] > 0, key
+    assert abs(d["ms_per_step"] * 1000.0 - (k["pack_k_us"] + k["pack_v_us"])) < 1e-3 * d["ms_per_step"] * 1000.0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
