@@ -200,10 +200,11 @@ def test_mix_v(qc, orc, bits, L, q_len, sparse):
 @pytest.mark.parametrize("L", [700, 40000, 70000])   # (70000: the token-split outlier phase of long 4-bit caches)
 @pytest.mark.parametrize("skew", ["low", "high", "33+9", "9+33", "one_channel", "mixed"])
 def test_mix_v_skewed_outlier_rows(qc, orc, bits, L, skew):
-    """The streaming p.V kernel lets the first / last unit group of a 4-bit launch read a 32-slot window of the
-    channel-sorted outlier rows from its end and takes the rest in a second pass when some token has more entries of
-    that group (kvq_mix_v.hip, sparse_phase): rows whose 42 entries sit entirely / mostly in one half of the channels,
-    rows that all name the same channels (same-address LDS adds), against the oracle."""
+    """The outlier phase of the streaming p.V kernel (kvq_mix_v.hip, sparse_phase: per-group rows, the straight-line
+    single-round form of one-unit-group launches, and -- 4 bit from 64K tokens -- the entries split by tokens between the
+    unit groups with extra slabs for the other group's channels; 3 / 2 bit take the one-workgroup-per-CU plan up to 48K
+    tokens): rows whose 42 entries sit entirely / mostly in one half of the channels, rows that all name the same
+    channels (same-address LDS adds), against the oracle."""
     n = 2 ** bits
     max_len = (L + 64 + 63) // 64 * 64          # aligned rows: the streaming kernel, not the row-per-lane fallback
     mat = _random_cache(bits, L, max_len, 5 + L)
