@@ -48,9 +48,6 @@
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24             // outlier phase: entries per lane and token block (one round of loads)
 #endif
-#ifndef KVQ_V_WIN
-#define KVQ_V_WIN 64            // development (profiles/r05_pv_outlier_phase.txt): slots of a row that the first / last of several unit groups would read from its end in sparse_phase_one
-#endif
 // (the experiment switches of rounds 2-3 -- wave priorities, 16-token chunks at 4 bit, the C++ look-up loops next to the
 //  hand-scheduled ones, DMA in one burst, the development ablations -- were measured neutral or slower and are gone;
 //  DESIGN.md 3 keeps the numbers)
