@@ -45,6 +45,9 @@
 #define KVQ_V_WGS 512           // workgroups the plan aims at (2 per CU)
 #define KVQ_V_WAVES 4           // waves per SIMD the register allocation aims at
 #define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles (64K tokens) the p.V workgroups merge the partials themselves
+#ifndef KVQ_V_WIDE_FROM
+#define KVQ_V_WIDE_FROM 49152   // cached tokens from which the 1024-lane geometry (kvq_mix_v_wide.hip) takes a decode step's p.V
+#endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24             // outlier phase: entries per lane and token block (one round of loads)
 #endif
@@ -1044,10 +1047,44 @@ static int merge_in_kernel_parts(bool sink_outputs) {
   return sink_outputs ? 0 : kMergeInKernelParts;
 }
 
+// kvq_mix_v_wide.hip: the one-workgroup-per-CU geometry with the outlier entries evaluated inside the dense loop
+bool mix_wide_ok(int bits, const MixArgs &a);
+int launch_mix_wide_bits(int bits, const MixArgs &a, float *mul, int accumulate, hipStream_t st, const FusedSoftmax *fs,
+                         const float *mz, int *n_slabs_out);
+// from how many cached tokens the wide geometry runs (KVQ_V_WIDE_FROM; KVQ_V_WIDE=0: never)
+static int64_t wide_from() {
+  static const int64_t v = [] {
+    const char *off = getenv("KVQ_V_WIDE");
+    if (off && off[0] == '0') return (int64_t)1 << 62;
+    const char *e = getenv("KVQ_V_WIDE_FROM");
+    return e ? (int64_t)atoll(e) : (int64_t)KVQ_V_WIDE_FROM;
+  }();
+  return v;
+}
+
 template <int BITS>
 static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, const FusedSoftmax *fs = nullptr) {
   using Cfg = VCfg<BITS>;
   Plan pl = plan_mix<BITS>(a.q_len, a.H, a.L);
+  if (a.L >= wide_from() && mix_wide_ok(BITS, a)) {
+    // (the workspace is the 512-lane plan's: the wide plan writes fewer slabs; the (max, normaliser) pairs keep their place)
+    const float *mzp = nullptr;
+    if (fs) {
+      float *mz = a.partial + (size_t)pl.n_ranges * (a.q_len == 1 ? pl.groups : a.q_len) * a.H * kHeadDim;
+      softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz, fs->v_sink, mul);
+      int rc0 = check_launch();
+      if (rc0) return rc0;
+      if (fs->v_sink != nullptr) accumulate = 1;     // the reduce adds the slabs onto the sink tokens' output
+      mzp = mz;
+    }
+    int n_slabs = 0;
+    int rc = launch_mix_wide_bits(BITS, a, mul, accumulate, st, fs, mzp, &n_slabs);
+    if (rc) return rc;
+    const int C = a.H * kHeadDim;
+    dim3 rgrid((C + 15) / 16, a.q_len);
+    mix_v_reduce_kernel<<<rgrid, 1024, 0, st>>>(a.partial, mul, n_slabs, a.q_len, C, accumulate);
+    return check_launch();
+  }
   a.tr = pl.tr;
   a.groups = pl.groups;
   a.n_units = pl.n_units;

@@ -10,6 +10,7 @@ for src in kvquant_amd/csrc/*.hip; do
   [ $b = kvq_score_k ] && fl="$2"
   [ $b = kvq_mix_v ] && fl="$3"
   [ $b = kvq_mix_v_api ] && fl="$3"
+  [ $b = kvq_mix_v_wide ] && fl="$3"
   if [ -z "$fl" ]; then objs="$objs kvquant_amd/_obj/$b.o"; continue; fi
   /opt/rocm/bin/hipcc $F $fl -c $src -o $d/$b.o || exit 1
   objs="$objs $d/$b.o"

@@ -240,7 +240,10 @@ def check_mix_v(path):
 
 def main():
     if len(sys.argv) > 1:
-        kernels, problems = check_mix_v(sys.argv[1]) if "mix_v" in os.path.basename(sys.argv[1]) else check(sys.argv[1])
+        if "mix_v_wide" in os.path.basename(sys.argv[1]):
+            kernels, problems = check_cfg(sys.argv[1], kernel_substr="mix_v_wide_kernel")
+        else:
+            kernels, problems = check_mix_v(sys.argv[1]) if "mix_v" in os.path.basename(sys.argv[1]) else check(sys.argv[1])
     else:
         kernels, problems = check(_compile("kvq_score_k.hip"))
         k2, p2 = check_mix_v(_compile("kvq_mix_v.hip"))
@@ -248,6 +251,9 @@ def main():
         # the fused decode kernel runs the mirror score tile body (loads in flight across head iterations) as its K phase
         k3, p3 = check_cfg(_compile("kvq_fused_decode.hip"), kernel_substr="fused_decode_kernel")
         kernels, problems = kernels + k3, problems + p3
+        # the one-workgroup-per-CU p.V kernel keeps a chunk's outlier entries in flight in registers across a whole chunk
+        k4, p4 = check_cfg(_compile("kvq_mix_v_wide.hip"), kernel_substr="mix_v_wide_kernel")
+        kernels, problems = kernels + k4, problems + p4
     print("%d kernels checked, %d problems" % (kernels, len(problems)))
     for p in problems:
         print("  " + p)
