@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--retrieval", action="store_true", help="plant a retrievable token and check it (config 5 proxy)")
     ap.add_argument("--time-every", type=int, default=11,
                     help="bracket every N-th layer's two matvec launches with HIP events (1 = all; the events cost time)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short legs over the other BASELINE configurations that the default 1-GPU line carries "
+                         "under `configs` (4K / 32K decode, nuq3 + 5 sinks at 128K, the 8K prefill, 1M tokens on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp16-baseline", action="store_true")
     ap.add_argument("--no-full-model", action="store_true",
@@ -966,6 +969,54 @@ def run_config(args, rank, world, dev, dist, label=None, with_baselines=True):
     return res
 
 
+def config_summary(r):
+    """one BASELINE configuration of the `configs` list of the default line: what the headline reports, in short"""
+    k = r.get("kernels", {})
+    out = {"label": r["config"].get("label"), "workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"],
+           "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+           "frac": r["roofline"]["frac"], "roofline_kernel": r["roofline"].get("kernel"),
+           "avg_launch_us": r["roofline"].get("avg_launch_us")}
+    if "roofline_step" in r:
+        out["step_frac"] = r["roofline_step"]["frac"]
+    for key in ("score_k_us", "mix_v_us", "fused_attend_us", "fused_merge_us", "pack_k_us", "pack_v_us", "pack_k_GBps",
+                "pack_v_GBps", "prefill_attention_us", "prefill_attention_TFLOPs",
+                "prefill_attention_frac_of_2500_TF_dense_fp16"):
+        if k.get(key) is not None:
+            out[key] = k[key]
+    if "retrieval" in r:
+        out["retrieval"] = r["retrieval"]
+    return out
+
+
+def other_configs(args, rank, world, dev, dist):
+    """The BASELINE configurations besides the headline, as short legs of the default run: config 2
+    (4K / 32K decode), config 3 (nuq3 + 5 fp16 sink tokens at 128K), config 4 (8K-token prefill: pack + MFMA attention)
+    and the 1M-token shape of config 5 on one GPU (8 of its 32 layers).  Same code path as the headline (run_config),
+    fewer steps, no baselines; `frac` is the dominant kernel's fraction of 8 TB/s from its in-stream event timers."""
+    base = dict(vars(args))
+    legs = [("config 2: 4K decode (32 layers, rotated)", 4096, 4, 0, 32, 10),
+            ("config 2: 32K decode", 32768, 4, 0, 32, 10),
+            ("config 3: nuq3 + 5 fp16 sink tokens, 128K decode", 131072, 3, 5, 32, 8),
+            ("config 5 shape on one GPU: 1M tokens, 8 of 32 layers", 1048576, 4, 0, 8, 4)]
+    out = []
+    for label, ctx, bits, sinks, layers, steps in legs:
+        if (ctx, bits, sinks, layers) == (args.ctx, args.bits, args.sinks, args.layers):
+            continue
+        a = argparse.Namespace(**base)
+        a.ctx, a.bits, a.sinks, a.layers, a.steps, a.warmup = ctx, bits, sinks, layers, steps, 2
+        a.compact, a.score_f16, a.retrieval = False, False, False
+        try:
+            r = run_config(a, rank, world, dev, dist, label=label, with_baselines=False)
+            out.append(config_summary(r))
+        except Exception as e:          # (a leg never takes the headline down)
+            out.append({"label": label, "error": "%s: %s" % (type(e).__name__, e)})
+    try:
+        out.append(config_summary(run_prefill_config(4, 8192, dev)))
+    except Exception as e:
+        out.append({"label": "prefill S=8192 nuq4 (config 4)", "error": "%s: %s" % (type(e).__name__, e)})
+    return out
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -1053,6 +1104,8 @@ def main():
         res = run_head_sharded(args, rank, world, dev, dist)
     else:
         res = run_config(args, rank, world, dev, dist)
+        if world == 1 and res is not None and not args.no_configs and not args.retrieval:
+            res["configs"] = other_configs(args, rank, world, dev, dist)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -46,7 +46,7 @@
 #define KVQ_V_WAVES 4           // waves per SIMD the register allocation aims at
 #define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles (64K tokens) the p.V workgroups merge the partials themselves
 #ifndef KVQ_V_WIDE_FROM
-#define KVQ_V_WIDE_FROM 49152   // cached tokens from which the 1024-lane geometry (kvq_mix_v_wide.hip) takes a decode step's p.V
+#define KVQ_V_WIDE_FROM 12288   // cached tokens from which the 1024-lane geometry (kvq_mix_v_wide.hip) takes a decode step's p.V
 #endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24             // outlier phase: entries per lane and token block (one round of loads)
@@ -1069,7 +1069,8 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   if (a.L >= wide_from() && mix_wide_ok(BITS, a)) {
     // (the workspace is the 512-lane plan's: the wide plan writes fewer slabs; the (max, normaliser) pairs keep their place)
     const float *mzp = nullptr;
-    if (fs) {
+    // the merge kernel: many score tiles, or sink tokens (whose probabilities and outputs it writes)
+    if (fs && (fs->n_sink > 0 || fs->n_parts > kMergeInKernelParts)) {
       float *mz = a.partial + (size_t)pl.n_ranges * (a.q_len == 1 ? pl.groups : a.q_len) * a.H * kHeadDim;
       softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz, fs->v_sink, mul);
       int rc0 = check_launch();

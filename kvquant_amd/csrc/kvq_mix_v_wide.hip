@@ -35,6 +35,9 @@
 #ifndef KVQ_W_BURST
 #define KVQ_W_BURST 0     // 1: the next tile's pieces in one burst behind the barrier instead of a piece per quad
 #endif
+#ifndef KVQ_W_PRIO
+#define KVQ_W_PRIO 0      // 1: wave priority = token slot (the youngest wave of a SIMD highest), 2: the reverse
+#endif
 #ifndef KVQ_W_ABL
 #define KVQ_W_ABL 0       // 1: no outlier evaluation, 2: no look-up loop, 4: no tile DMA (results wrong)
 #endif
@@ -194,6 +197,14 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
   }
   const int64_t t1 = (t0 + (int64_t)n_chunks * CT < a.L) ? t0 + (int64_t)n_chunks * CT : a.L;
   if (lds_addr(smem) != 0) __builtin_trap();   // (the instruction immediates below assume the one static LDS array at 0)
+#if KVQ_W_PRIO
+  {
+    const int pr = KVQ_W_PRIO == 1 ? sl : 3 - sl;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+#endif
 
 #if KVQ_TRACE
   // development: cycles per wave in [0] data waits, [1] barriers, [2] entries + look-ahead issue + score conversion,
@@ -231,66 +242,122 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
   // ---- outlier entries of a chunk: entry e = round * NT + tid of its CT * n_out entries
   const int NE = sparse ? CT * a.n_out : 0;
   uint32_t e_idx[Cfg::E_R], e_val[Cfg::E_R];
-  auto issue_entries = [&](int64_t c0) {
-    // (clamped to the rows that exist; without sparse rows: the same number of loads from a valid address)
-    const int64_t lim = (a.max_len - c0) * (int64_t)a.n_out;
+  // round r of the chunk at c0 (clamped to the rows that exist; without sparse rows: the same loads from a valid address)
+  auto issue_entry_round = [&](int r, int64_t c0) {
+    const int64_t lim64 = (a.max_len - c0) * (int64_t)a.n_out;
+    const unsigned lim = lim64 > 0x7fffffff ? 0x7fffffffu : (unsigned)lim64;        // (wave-uniform)
     const void *bi = sparse ? static_cast<const void *>(a.idx + c0 * a.n_out) : static_cast<const void *>(a.lut_rows);
     const void *bv = sparse && !compact ? static_cast<const void *>(a.outliers + c0 * a.n_out) : bi;
+    unsigned e = (unsigned)(r * Cfg::NT + tid);
+    if (!sparse) e = 0;
+    else if (e >= lim) e = lim - 1;
+    entry_load(e_idx[r], bi, e * 4u);
+    entry_load(e_val[r], bv, e * 4u);
+  };
+  auto hold_entries = [&]() {
 #pragma unroll
-    for (int r = 0; r < Cfg::E_R; r++) {
-      unsigned e = (unsigned)(r * Cfg::NT + tid);
-      if (!sparse) e = 0;
-      else if ((int64_t)e >= lim) e = (unsigned)(lim - 1);
-      entry_load(e_idx[r], bi, e * 4u);
-      entry_load(e_val[r], bv, e * 4u);
-    }
+    for (int r = 0; r < Cfg::E_R; r++) asm volatile("" ::"v"(e_idx[r]), "v"(e_val[r]));
   };
   const int c_lo = u0 * CH, cn = n_units_valid * CH;
-  auto eval_entries = [&](int pbuf, int64_t c0) {
-    long long *sacc = reinterpret_cast<long long *>(smem + Cfg::ACC_OFF);
-    const float *pl = reinterpret_cast<const float *>(smem + Cfg::p_off(0)) + pbuf * (Cfg::P_B / 4);
+  // Evaluation of one round of entries, in two steps that ride between the look-up batches of the dense loop (every wave of
+  // the workgroup is in the same phase at the same time: as a block of its own behind the barrier this arithmetic ran with
+  // the LDS idle -- 2400 of 8750 cycles per chunk, profiles/r06_c_wide_trace.txt):
+  //   ent_issue(r):  entry -> (token, channel, head), the LDS read of its probability (hand-issued: lands behind the batch
+  //                  in flight, covered by the loop's next counted wait)
+  //   ent_commit():  value * probability -> 32.32 fixed point -> ds_add_u64 into the channel's accumulator
+  float ent_pt = 0.f;
+  uint32_t ent_acc = 0;
+  auto ent_issue = [&](int r, int pbuf, int64_t c0) {
+    asm volatile("" : "+v"(e_idx[r]), "+v"(e_val[r]));       // (landed: the sub-stage's wait covers them)
+    const unsigned e = (unsigned)(r * Cfg::NT + tid);
+    const unsigned tl = __umulhi(e, a.n_out_magic);           // token within the chunk
+    const uint32_t w = e_idx[r];
+    const unsigned ch = compact ? (w & 0xffffu) : w;
+    const unsigned rel = ch - (unsigned)c_lo;
+    const unsigned rem = (unsigned)(t1 - c0);                  // tokens of the range left from the chunk's start (wave-uniform, >= 1)
+    const bool mine = (int)e < NE && rel < (unsigned)cn && tl < rem;
+    const unsigned hh = mine ? (rel >> 7) : 0u;
+    const uint32_t p_addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + (hh * CT + (mine ? tl : 0u)) * 4u;
+    // (not mine -- another group's channel, a padding slot, a token past the range: its product goes to a dummy accumulator)
+    ent_acc = (uint32_t)Cfg::ACC_OFF + (mine ? rel : (unsigned)Cfg::GC + (tid & 63u)) * 8u;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(ent_pt) : "v"(p_addr) : "memory");
+  };
+  auto ent_commit = [&](int r) {
+    asm volatile("" : "+v"(ent_pt));                          // (landed: a counted wait of the loop has passed)
+    const float v = compact ? __half2float(__ushort_as_half((unsigned short)(e_idx[r] >> 16))) : __uint_as_float(e_val[r]);
+    // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
+    const float x = v * ent_pt;
+    const float fl = floorf(x);
+    const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
+    const int hi = (int)fl;
+    const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
+    asm volatile("ds_add_u64 %0, %1" ::"v"(ent_acc), "v"(fx) : "memory");
+  };
+  static_assert(Cfg::E_R == 2 && Cfg::QPL == 2, "one round of entries per quad");
+
+  // ---- fused softmax: the (max, 1 / normaliser) of the head whose scores this lane converts -- from the merge kernel's
+  // pairs (a.mz), or, few score tiles and no sink tokens, merged here from the score kernel's partials by the 32 lanes
+  // that convert the head's scores (one launch less: what a short cache's step is made of)
+  float myM = 0.f, myZ = 1.f;
+  auto load_mz = [&]() {
+    if constexpr (FUSED) {
+      int hc = h0 + tid / CT;
+      if (hc >= a.H) hc = a.H - 1;
+      if (a.mz != nullptr) {
+        const float2 t = reinterpret_cast<const float2 *>(a.mz)[hc];
+        myM = t.x;
+        myZ = 1.0f / t.y;
+      } else {
+        static_assert(CT == 32, "a head's scores of a chunk are converted by half a wave");
+        const float2 *pr = reinterpret_cast<const float2 *>(a.parts) + (int64_t)hc * a.n_parts;
+        float M = -INFINITY, Z = 0.f;
+        constexpr int MB = 8;
+        for (int i0 = tid & 31; i0 < a.n_parts; i0 += 32 * MB) {
+          float2 ms[MB];
 #pragma unroll
-    for (int r = 0; r < Cfg::E_R; r++) {
-      asm volatile("" : "+v"(e_idx[r]), "+v"(e_val[r]));       // (landed: the sub-stage's wait covers them)
-      const unsigned e = (unsigned)(r * Cfg::NT + tid);
-      const unsigned tl = __umulhi(e, a.n_out_magic);           // token within the chunk
-      const uint32_t w = e_idx[r];
-      const unsigned ch = compact ? (w & 0xffffu) : w;
-      const float v = compact ? __half2float(__ushort_as_half((unsigned short)(w >> 16))) : __uint_as_float(e_val[r]);
-      const unsigned rel = ch - (unsigned)c_lo;
-      const bool mine = (int)e < NE && rel < (unsigned)cn && c0 + tl < t1;
-      const unsigned hh = mine ? (rel >> 7) : 0u;
-      const float pt = pl[hh * CT + (mine ? tl : 0u)];
-      // x -> 32.32 fixed point without 64-bit float math: floor part + exact 32-bit fraction
-      const float x = mine ? v * pt : 0.f;
-      const float fl = floorf(x);
-      const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
-      const int hi = (int)fl;
-      const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
-      const unsigned slot = mine ? rel : (unsigned)Cfg::GC + (tid & 63u);    // (not mine: + 0 into a dummy)
-      atomicAdd(reinterpret_cast<unsigned long long *>(&sacc[slot]), fx);
+          for (int k = 0; k < MB; k++) ms[k] = (i0 + 32 * k < a.n_parts) ? pr[i0 + 32 * k] : make_float2(-INFINITY, 0.f);
+#pragma unroll
+          for (int k = 0; k < MB; k++)
+            if (ms[k].x > -INFINITY) {
+              const float mn = fmaxf(M, ms[k].x);
+              Z = Z * mz_w(M - mn) + ms[k].y * mz_w(ms[k].x - mn);
+              M = mn;
+            }
+        }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+          const float mo = __shfl_xor(M, d), zo = __shfl_xor(Z, d);
+          const float mn = fmaxf(M, mo);
+          Z = (mn == -INFINITY) ? 0.f : Z * mz_w(M - mn) + zo * mz_w(mo - mn);
+          M = mn;
+        }
+        myM = M;
+        myZ = 1.0f / Z;
+      }
     }
   };
-
-  // ---- fused softmax: the (max, 1 / normaliser) of the head whose scores this lane converts
-  float myM = 0.f, myZ = 1.f;
-  if constexpr (FUSED) {
-    int hc = h0 + tid / CT;
-    if (hc >= a.H) hc = a.H - 1;
-    const float2 t = reinterpret_cast<const float2 *>(a.mz)[hc];
-    myM = t.x;
-    myZ = 1.0f / t.y;
-  }
   auto convert_p = [&](int pbuf, int64_t c0) {
     float *pp = reinterpret_cast<float *>(smem + Cfg::p_off(0)) + pbuf * (Cfg::P_B / 4) + tid;
     const float x = *pp;
     *pp = (c0 + (tid % CT) < t1) ? prob_of(x, a.inv, myM, myZ) : 0.f;
   };
 
+  // the same conversion riding in the loop: the raw score is read behind one look-up batch, converted behind others
+  float cv_raw = 0.f;
+  auto cv_issue = [&](int pbuf) {
+    const uint32_t addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + (uint32_t)tid * 4u;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(cv_raw) : "v"(addr) : "memory");
+  };
+  auto cv_commit = [&](int pbuf, int64_t c0) {
+    asm volatile("" : "+v"(cv_raw));
+    const uint32_t addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + (uint32_t)tid * 4u;
+    const float pr = (c0 + (tid % CT) < t1) ? prob_of(cv_raw, a.inv, myM, myZ) : 0.f;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(pr) : "memory");
+  };
+
   // ---- issue of everything a chunk needs besides its tiles: codebook rows, probabilities / scores, entries
   auto issue_chunk_extras = [&](int cnext, int lut_buf, int pbuf_next) {
     const int64_t cn0 = t0 + (int64_t)cnext * CT;
-    issue_entries(cn0);
     wide_lut<BITS>(a, dl, cn0, Cfg::lut_off(0) + lut_buf * Cfg::LUT_B, wave, cn0 <= fast_end, f_lut);
     // fused: the scores travel one chunk further ahead (converted during the chunk before they are used)
     const int64_t pc0 = FUSED ? cn0 + CT : cn0;
@@ -327,8 +394,10 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
   wide_lut<BITS>(a, dl, t0, Cfg::lut_off(0), wave, t0 <= fast_end, f_lut);
   wide_p<BITS>(psrc, a, dl, t0, h0, Cfg::p_off(0), wave);
   if constexpr (FUSED) wide_p<BITS>(psrc, a, dl, t0 + CT, h0, Cfg::p_off(1), wave);
-  issue_entries(t0);
+  issue_entry_round(0, t0);
+  issue_entry_round(1, t0);
   if constexpr (NU == 2) issue_tile_all(0, 1, 1);          // (the last T_OPS operations: the loop's first wait leaves them in flight)
+  load_mz();                                               // (behind the first requests)
   if constexpr (NU == 2) vm_wait<Cfg::T_OPS>(); else vm_wait<0>();
   __syncthreads();
   if constexpr (FUSED) convert_p(0, t0);                // (visible after the first sub-stage's barrier)
@@ -359,8 +428,8 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
   // Every sub-stage issues its look-ahead UNCONDITIONALLY -- the last chunk of a range re-requests itself (L2 hits, landing in
   // ring slots and registers nobody reads) -- so that there is one path, on which the number of operations in flight at every
   // wait is a constant, and no control flow between a hand-issued load and the wait that covers it.
-  auto substage = [&](auto LP_, auto U_, int c) {
-    constexpr int LP = decltype(LP_)::value, U = decltype(U_)::value;
+  auto substage = [&](auto LP_, auto U_, auto HI_, int c) {
+    constexpr int LP = decltype(LP_)::value, U = decltype(U_)::value, HI = decltype(HI_)::value;
     const int64_t c0 = t0 + (int64_t)c * CT;
     const int cnx = (c + 1 < n_chunks) ? c + 1 : c;     // the chunk whose data this one requests
     // ---- the sub-stage's rows (and with U == 0 the chunk's codebook rows, probabilities, entries) have landed
@@ -376,13 +445,35 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
     __syncthreads();
     KVQ_W_STAMP(1);
     const int slot_next = (slot + NS - 1) % NS;        // ring slot of sub-stage s + NS - 1 (the one freed by the barrier)
-    if constexpr (U == 0) {
-      if (sparse && !(KVQ_W_ABL & 1)) eval_entries(pcur, c0);
-      issue_chunk_extras(cnx, 1 - LP, FUSED ? (pcur + 2) % 3 : (pcur + 1) % 3);
-      if constexpr (FUSED) {
-        if (c + 1 < n_chunks) convert_p((pcur + 1) % 3, c0 + CT);
+    // Positions inside the look-up loop where the chunk's other work rides (K = 0: behind the quad's first wait, in front
+    // of its first batch; K = 1..3: in front of the first batch of the quad's token K): each step issues at most one LDS
+    // operation, immediately IN FRONT of a look-up batch -- operations return in order, so every counted wait that leaves
+    // that batch in flight has waited for the step's operation too.
+    //   4 bit (two sub-stages per chunk): sub-stage 0 evaluates entry round qq in quad qq, sub-stage 1 converts the next
+    //   chunk's scores; 3 / 2 bit: everything in the one sub-stage.
+    const bool conv_on = FUSED && c + 1 < n_chunks;
+    auto hook = [&](auto QQ, auto K_) {
+      constexpr int qq = decltype(QQ)::value, k = decltype(K_)::value;
+      constexpr int K_ENT = NU == 2 ? 2 : 1;                 // entries: issue at K_ENT, commit at K_ENT + 1
+      if constexpr (NU == 1 || U == 0) {
+        const bool on = sparse && qq * Cfg::NT + wave * 64 < NE && !(KVQ_W_ABL & 1);        // (this wave has entries in round qq)
+        if constexpr (k == K_ENT) { if (on) ent_issue(qq, pcur, c0); }
+        if constexpr (k == K_ENT + 1) {
+          if (on) ent_commit(qq);
+          // the round's registers are free: the same round of the next chunk (in flight until that chunk's first wait)
+          issue_entry_round(qq, t0 + (int64_t)cnx * CT);
+        }
       }
-    }
+      if constexpr (FUSED && (NU == 1 || U == 1) && qq == Cfg::QPL - 1) {
+        if constexpr (k == 2) { if (conv_on) cv_issue((pcur + 1) % 3); }
+        if constexpr (k == 3) { if (conv_on) cv_commit((pcur + 1) % 3, c0 + CT); }
+      }
+    };
+    constexpr std::integral_constant<int, 0> K0{};
+    constexpr std::integral_constant<int, 1> K1{};
+    constexpr std::integral_constant<int, 2> K2{};
+    constexpr std::integral_constant<int, 3> K3{};
+    if constexpr (U == 0) issue_chunk_extras(cnx, 1 - LP, FUSED ? (pcur + 2) % 3 : (pcur + 1) % 3);
     if (!FUSED && U == 0 && t1 - c0 < CT) {            // ragged last chunk: zero the probabilities past the end once
       float *pb = reinterpret_cast<float *>(smem + Cfg::p_off(0)) + pcur * (Cfg::P_B / 4);
       const int rem = (int)(t1 - c0);
@@ -420,13 +511,16 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
         uint32_t we, wo, ua[8], ub[8];
         float va[8], vb[8];
         lds_wait<0>();
+        hook(QQ, K0);
         nib_prep(we, wo, wq[cur].x, slotpat); nib_extract(ua, we, wo); lut_read8<L0 + (qq * 4 + 0) * TS>(va, ua);
         nib_prep(we, wo, wq[cur].y, slotpat); nib_extract(ub, we, wo); lut_read8<L0 + (qq * 4 + 1) * TS>(vb, ub);
         // a quad's share of the next tile's DMA, behind 16 look-ups in flight
         piece(QQ);
         lds_wait<8>(); fmac8(acc[U], va, pq[cur].x);
+        hook(QQ, K2);
         nib_prep(we, wo, wq[cur].z, slotpat); nib_extract(ua, we, wo); lut_read8<L0 + (qq * 4 + 2) * TS>(va, ua);
         lds_wait<8>(); fmac8(acc[U], vb, pq[cur].y);
+        hook(QQ, K3);
         nib_prep(we, wo, wq[cur].w, slotpat); nib_extract(ub, we, wo); lut_read8<L0 + (qq * 4 + 3) * TS>(vb, ub);
         if constexpr (qq + 1 < Cfg::QPL) {
           lds_read16<S0>(wq[1 - cur], taddr[qq + 1][0] + tb);
@@ -442,8 +536,7 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
     }
     if constexpr (BITS == 3 && !(KVQ_W_ABL & 2)) {
       // slots 2, 3: their codebook rows sit 2 * N * 4 bytes further (the 6-bit look-up fields carry one slot bit)
-      auto body = [&](auto HI_) {
-        constexpr int HI = decltype(HI_)::value;
+      {
         constexpr int L1 = L0 + HI * 2 * N * 4;
         const uint32_t slot3 = (uint32_t)(sl & 1) * 0x20820820u;
         uint4 wq[2][3];
@@ -457,6 +550,7 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
           uint32_t s1, s2, e1, o1, e2, o2, ua[8];
           float va[8], vb[8];
           lds_wait<0>();
+          hook(QQ, K0);
           tri_streams(s1, s2, wq[cur][0].x, wq[cur][1].x, wq[cur][2].x, hf);
           tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
           tri_extract_a(ua, e1, o1); lut_read8<L1 + (qq * 4 + 0) * TS>(va, ua);
@@ -470,18 +564,21 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
           tri_streams(s1, s2, wq[cur][0].y, wq[cur][1].y, wq[cur][2].y, hf);
           tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
           lds_wait<8>(); fmac8_at<0>(acc[U], va, pq[cur].x);
+          hook(QQ, K1);
           tri_extract_a(ua, e1, o1); lut_read8<L1 + (qq * 4 + 1) * TS>(va, ua);
           lds_wait<8>(); fmac8_at<8>(acc[U], vb, pq[cur].x);
           tri_extract_b(ua, e1, o1, e2, o2); lut_read8<L1 + (qq * 4 + 1) * TS>(vb, ua);
           tri_streams(s1, s2, wq[cur][0].z, wq[cur][1].z, wq[cur][2].z, hf);
           tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
           lds_wait<8>(); fmac8_at<0>(acc[U], va, pq[cur].y);
+          hook(QQ, K2);
           tri_extract_a(ua, e1, o1); lut_read8<L1 + (qq * 4 + 2) * TS>(va, ua);
           lds_wait<8>(); fmac8_at<8>(acc[U], vb, pq[cur].y);
           tri_extract_b(ua, e1, o1, e2, o2); lut_read8<L1 + (qq * 4 + 2) * TS>(vb, ua);
           tri_streams(s1, s2, wq[cur][0].w, wq[cur][1].w, wq[cur][2].w, hf);
           tri_prep(e1, o1, s1, slot3); tri_prep(e2, o2, s2, slot3);
           lds_wait<8>(); fmac8_at<0>(acc[U], va, pq[cur].z);
+          hook(QQ, K3);
           tri_extract_a(ua, e1, o1); lut_read8<L1 + (qq * 4 + 3) * TS>(va, ua);
           lds_wait<8>(); fmac8_at<8>(acc[U], vb, pq[cur].z);
           tri_extract_b(ua, e1, o1, e2, o2); lut_read8<L1 + (qq * 4 + 3) * TS>(vb, ua);
@@ -496,8 +593,7 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
             lds_wait<0>(); fmac8_at<8>(acc[U], vb, pq[cur].w);
           }
         });
-      };
-      if (sl >> 1) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});
+      }
     }
     if constexpr (BITS == 2 && !(KVQ_W_ABL & 2)) {
       const uint32_t slot2 = (uint32_t)sl * 0x10101010u;
@@ -511,22 +607,26 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
         uint32_t pk[4], ua[8];
         float va[8], vb[8];
         lds_wait<0>();
+        hook(QQ, K0);
         duo_prep(pk, wq[cur].x, slot2);
         duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 0) * TS>(va, ua);
         duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 0) * TS>(vb, ua);
         piece(QQ);
         duo_prep(pk, wq[cur].y, slot2);
         lds_wait<8>(); fmac8_at<0>(acc[U], va, pq[cur].x);
+        hook(QQ, K1);
         duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 1) * TS>(va, ua);
         lds_wait<8>(); fmac8_at<8>(acc[U], vb, pq[cur].x);
         duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 1) * TS>(vb, ua);
         duo_prep(pk, wq[cur].z, slot2);
         lds_wait<8>(); fmac8_at<0>(acc[U], va, pq[cur].y);
+        hook(QQ, K2);
         duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 2) * TS>(va, ua);
         lds_wait<8>(); fmac8_at<8>(acc[U], vb, pq[cur].y);
         duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 2) * TS>(vb, ua);
         duo_prep(pk, wq[cur].w, slot2);
         lds_wait<8>(); fmac8_at<0>(acc[U], va, pq[cur].z);
+        hook(QQ, K3);
         duo_extract_a(ua, pk); lut_read8<L0 + (qq * 4 + 3) * TS>(va, ua);
         lds_wait<8>(); fmac8_at<8>(acc[U], vb, pq[cur].z);
         duo_extract_b(ua, pk); lut_read8<L0 + (qq * 4 + 3) * TS>(vb, ua);
@@ -544,18 +644,26 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
     KVQ_W_STAMP(3);
     slot = (slot + 1) % NS;
   };
-  auto chunk = [&](auto LP_, int c) {
-    substage(LP_, std::integral_constant<int, 0>{}, c);
-    if constexpr (NU == 2) substage(LP_, std::integral_constant<int, 1>{}, c);
-    pcur = (pcur + 1) % 3;
+  // HI: the second bit of the token slot (3 bit only: the 6-bit look-up fields carry one slot bit, the other one selects a
+  // different immediate in every look-up -- slots 2 and 3 run their own copy of the WHOLE loop: no control flow inside it)
+  auto run = [&](auto HI_) {
+    auto chunk = [&](auto LP_, int c) {
+      substage(LP_, std::integral_constant<int, 0>{}, HI_, c);
+      if constexpr (NU == 2) substage(LP_, std::integral_constant<int, 1>{}, HI_, c);
+      pcur = (pcur + 1) % 3;
+    };
+    for (int c = 0; c < n_chunks; c += 2) {
+      chunk(std::integral_constant<int, 0>{}, c);
+      if (c + 1 < n_chunks) chunk(std::integral_constant<int, 1>{}, c + 1);
+    }
+    // the last chunk's look-ahead has landed (the ring is about to be overwritten by the slot sums); its entry registers stay
+    // reserved until here
+    vm_wait<0>();
+    hold_entries();
   };
-  for (int c = 0; c < n_chunks; c += 2) {
-    chunk(std::integral_constant<int, 0>{}, c);
-    if (c + 1 < n_chunks) chunk(std::integral_constant<int, 1>{}, c + 1);
-  }
+  if (BITS == 3 && (sl >> 1)) run(std::integral_constant<int, BITS == 3 ? 1 : 0>{}); else run(std::integral_constant<int, 0>{});
 
   // ---- sum the token slots through LDS (aliases the tile ring), add the outlier sums, one slab per workgroup
-  vm_wait<0>();          // (the last chunk's look-ahead has landed: the ring is about to be overwritten)
   __syncthreads();
   float *red = reinterpret_cast<float *>(smem + Cfg::tile_off(0));
 #pragma unroll
@@ -625,7 +733,9 @@ int launch_mix_wide(MixArgs a, float *mul, int accumulate, hipStream_t st, const
   if (fs) {
     a.scores = fs->scores;
     a.inv = fs->inv;
-    a.mz = mz;
+    a.mz = mz;            // (null: the workgroups merge the partials themselves)
+    a.parts = fs->parts;
+    a.n_parts = fs->n_parts;
   }
   wa.m = a;
   dim3 grid(n_ranges * a.groups), block(Cfg::NT);

@@ -24,7 +24,8 @@ def _run(*args):
 def test_bench_line_contract():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    d = _run("--ctx", "2048", "--layers", "2", "--steps", "3", "--warmup", "1", "--cpu-sample-tokens", "256")
+    d = _run("--ctx", "2048", "--layers", "2", "--steps", "3", "--warmup", "1", "--cpu-sample-tokens", "256", "--no-configs")
+    assert "configs" not in d
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "kernels", "full_model", "fp16_baseline"):
         assert key in d, key
@@ -41,6 +42,27 @@ def test_bench_line_contract():
     fm = d["full_model"]
     assert "error" not in fm, fm
     assert fm["tokens_per_s"] > 0 and fm["layers"] == 2
+
+
+def test_bench_line_carries_every_baseline_config():
+    """The default 1-GPU line carries the other BASELINE configurations as short legs under `configs`:
+    config 2 at 4K and 32K, config 3 (nuq3 + 5 sinks at 128K), the 1M-token shape of config 5 on one GPU, config 4 (prefill)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run("--ctx", "2048", "--layers", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fp16-baseline",
+             "--no-full-model")
+    cfgs = d["configs"]
+    assert len(cfgs) == 5, [c.get("label") for c in cfgs]
+    for c in cfgs:
+        assert "error" not in c, c
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and 0 < c["frac"] < 1, c
+    labels = " | ".join(c["label"] for c in cfgs)
+    for want in ("4K decode", "32K decode", "nuq3 + 5 fp16 sink tokens, 128K", "1M tokens", "prefill S=8192"):
+        assert want in labels, (want, labels)
+    decode = [c for c in cfgs if "decode" in c["label"] or "1M" in c["label"]]
+    assert all(("score_k_us" in c and "mix_v_us" in c) or "fused_attend_us" in c for c in decode), decode
+    pre = [c for c in cfgs if "prefill" in c["label"]][0]
+    assert pre["pack_k_us"] > 0 and pre["pack_v_us"] > 0 and pre["prefill_attention_TFLOPs"] > 0
 
 
 def test_bench_head_sharded_single_rank():

@@ -21,8 +21,8 @@ try:
     j = json.load(open(out))
 except Exception:
     j = {}
-for key, pat in (("score_k", "score_k_kernel"), ("mix_v", "mix_v_kernel")):
-    ks = [k for k in vals if pat in k and "FETCH_SIZE" in vals[k]]
+for key, pat in (("score_k", r"score_k_kernel"), ("mix_v", r"mix_v(_wide)?_kernel")):
+    ks = [k for k in vals if re.search(pat, k) and "FETCH_SIZE" in vals[k]]
     if not ks:
         continue
     k = max(ks, key=lambda n: vals[n]["FETCH_SIZE"])
