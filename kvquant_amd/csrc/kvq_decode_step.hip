@@ -230,13 +230,15 @@ int kvq_head_shard_step(const kvq_layer *full, const kvq_layer *shard, int h0, i
       full->thr_k != shard->thr_k || col < 0 || col >= shard->max_len)
     return KVQ_EINVAL;
   if (!full->koutliers || !full->voutliers || !shard->koutliers || !shard->voutliers) return KVQ_EINVAL;   // (reference outlier format)
-  int rc = kvq_append_kv_fused(full, 0, k, v, acts_are_half, stream);
-  if (rc) return rc;
-  // the extract of the staged column and the shard's query tables (+ fp16 sink scores) as ONE launch
-  if (!q || !workspace || reinterpret_cast<uintptr_t>(workspace) % 256 ||
+  // (every argument is checked before the first launch: a refused call leaves the staging column and the shard untouched)
+  if (!q || !k || !v || !out) return KVQ_EINVAL;
+  if (!workspace || reinterpret_cast<uintptr_t>(workspace) % 256 ||
       workspace_bytes < kvq_decode_step_workspace_bytes(shard->bits, shard->H, shard->hd, col + 1))
     return KVQ_EWORKSPACE;
   if (sinks != nullptr && sinks->n_sink > 0 && (!sinks->k_sink || !sinks->sink_scores)) return KVQ_EINVAL;
+  int rc = kvq_append_kv_fused(full, 0, k, v, acts_are_half, stream);
+  if (rc) return rc;
+  // the extract of the staged column and the shard's query tables (+ fp16 sink scores) as ONE launch
   const kvq_vopts *vn = full->vnorm;
   const kvq_vopts *sn = shard->vnorm;
   ExtractArgs a;

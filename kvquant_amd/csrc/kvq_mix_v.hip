@@ -116,7 +116,10 @@ __global__ __launch_bounds__(512, KVQ_V_WAVES) void mix_v_kernel(MixArgs a) {
   // order, one's latency-bound phase hides behind the other's look-ups (nuq3 p.V + reduce at 128K: 84 us alternating,
   // 91 us with every phase at the end).  The groups of a range (blocks 8 apart) have the same parity: they read the
   // range's entries at about the same time.
-  const bool sparse_first = !FUSED && sparse && (blockIdx.x & 1);
+  // (round 6: long caches run kvq_mix_v_wide.hip, whose outlier entries ride in the loop; what is left for this kernel --
+  //  short caches, q_len > 1 -- keeps the phase behind the loop in every workgroup: the alternating order bought nothing
+  //  there and cost the non-fused 2 / 3-bit instantiations 8 spilled VGPRs)
+  constexpr bool sparse_first = false;
   if (!sparse_first) issue_chunk<BITS>(a, dl, lds0, 0, t0, row_base, n_rows_valid, h0, b, !FUSED);
   const float2 *mz = reinterpret_cast<const float2 *>(smem + Cfg::SMEM_B);   // FUSED: (max, normaliser) per head
   float myM = 0.f, myZ = 1.f;                                                  // ... of the head this lane converts for

@@ -66,7 +66,13 @@ struct WCfg {
   static constexpr int GC = GU * CH;                     // channels per unit group (4096)
   static constexpr int HW = GC / kHeadDim;               // heads per unit group (32)
   static constexpr int LUT_B = CT * N * 4;
-  static constexpr int P_B = HW * CT * 4;                // 4 KB = one element per lane
+  // probabilities of a chunk: [head][token], the rows of two consecutive heads adjacent (one 256-byte DMA piece), the
+  // pieces P_PIECE = 288 bytes apart: the lanes of a ds_read_b128 group cover four consecutive heads, and with 256-byte
+  // pieces heads h and h + 2 sat in the same banks (a two-way conflict on every probability read: 2.1 M of the kernel's
+  // 23 M LDS cycles, profiles/r06_g_pmc_bench.txt)
+  static constexpr int P_PIECE = 288;
+  static constexpr int P_B = HW / 2 * P_PIECE;           // 4.5 KB; one element per lane
+  static constexpr int p_byte(int h, int t) { return (h >> 1) * P_PIECE + (h & 1) * (CT * 4) + t * 4; }
   static constexpr int NPB = 3;
   static constexpr int lut_off(int b) { return b * LUT_B; }
   static constexpr int p_off(int b) { return 2 * LUT_B + b * P_B; }
@@ -79,7 +85,7 @@ struct WCfg {
   static constexpr int LUT_LANES = LUT_B / 16;           // lanes that fetch 16 B of the codebook rows
   static constexpr int E_R = 2;                          // entry rounds (n_out * CT <= E_R * NT)
   static constexpr int E_OPS = 2 * E_R;                  // entry loads per wave and chunk (index + value)
-  static_assert(P_B / 4 == NT, "one probability per lane and chunk");
+  static_assert(HW * CT == NT, "one probability per lane and chunk");
   static_assert(TILE_B % (1024 * NW) == 0, "every wave issues the same number of tile pieces");
   static_assert(RED_B <= NS * TILE_B, "slot sums alias the tile ring");
   static_assert(SMEM_B <= 160 * 1024, "one workgroup per CU");
@@ -150,7 +156,7 @@ __device__ __forceinline__ void wide_p(const float *src, const MixArgs &a, const
   const uint32_t toff = (uint32_t)(lim_L <= 0 ? 0 : ((int)d.p_tok < lim_L ? (int)d.p_tok : lim_L - 1));
   int hr = (int)d.p_head;
   if (h0 + hr >= a.H) hr = a.H - 1 - h0;
-  dma4(gbase, ((uint32_t)hr * (uint32_t)a.L + toff) * 4u, dst + wave * 256);
+  dma4(gbase, ((uint32_t)hr * (uint32_t)a.L + toff) * 4u, dst + wave * WCfg<BITS>::P_PIECE);
 }
 
 // outlier entries of a chunk, in flight in registers for a whole chunk: hand-issued loads (hipcc must not put them on
@@ -277,7 +283,8 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
     const unsigned rem = (unsigned)(t1 - c0);                  // tokens of the range left from the chunk's start (wave-uniform, >= 1)
     const bool mine = (int)e < NE && rel < (unsigned)cn && tl < rem;
     const unsigned hh = mine ? (rel >> 7) : 0u;
-    const uint32_t p_addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + (hh * CT + (mine ? tl : 0u)) * 4u;
+    const uint32_t p_addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + (hh >> 1) * (unsigned)Cfg::P_PIECE + (hh & 1u) * (CT * 4u) +
+                            (mine ? tl : 0u) * 4u;
     // (not mine -- another group's channel, a padding slot, a token past the range: its product goes to a dummy accumulator)
     ent_acc = (uint32_t)Cfg::ACC_OFF + (mine ? rel : (unsigned)Cfg::GC + (tid & 63u)) * 8u;
     asm volatile("ds_read_b32 %0, %1" : "=v"(ent_pt) : "v"(p_addr) : "memory");
@@ -336,8 +343,10 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
       }
     }
   };
+  // (element tid of a p buffer = what this lane's DMA piece brought: piece tid / 64, lane tid % 64)
+  const uint32_t p_elem = (uint32_t)((tid >> 6) * Cfg::P_PIECE + (tid & 63) * 4);
   auto convert_p = [&](int pbuf, int64_t c0) {
-    float *pp = reinterpret_cast<float *>(smem + Cfg::p_off(0)) + pbuf * (Cfg::P_B / 4) + tid;
+    float *pp = reinterpret_cast<float *>(smem + Cfg::p_off(0) + pbuf * Cfg::P_B + p_elem);
     const float x = *pp;
     *pp = (c0 + (tid % CT) < t1) ? prob_of(x, a.inv, myM, myZ) : 0.f;
   };
@@ -345,12 +354,12 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
   // the same conversion riding in the loop: the raw score is read behind one look-up batch, converted behind others
   float cv_raw = 0.f;
   auto cv_issue = [&](int pbuf) {
-    const uint32_t addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + (uint32_t)tid * 4u;
+    const uint32_t addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + p_elem;
     asm volatile("ds_read_b32 %0, %1" : "=v"(cv_raw) : "v"(addr) : "memory");
   };
   auto cv_commit = [&](int pbuf, int64_t c0) {
     asm volatile("" : "+v"(cv_raw));
-    const uint32_t addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + (uint32_t)tid * 4u;
+    const uint32_t addr = (uint32_t)(Cfg::p_off(0) + pbuf * Cfg::P_B) + p_elem;
     const float pr = (c0 + (tid % CT) < t1) ? prob_of(cv_raw, a.inv, myM, myZ) : 0.f;
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(pr) : "memory");
   };
@@ -385,11 +394,7 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
     static_for<0, Cfg::T_OPS>([&](auto K) { wide_tile_piece<BITS, decltype(K)::value>(a, dl, f_tile, c0, ts.row0, ts.nrv, dst, wave, ts.fast); });
   };
 
-  // ---- prologue: zero the accumulators, first tiles, codebook rows, scores, entries
-  {
-    uint32_t *z = reinterpret_cast<uint32_t *>(smem + Cfg::ACC_OFF);
-    for (int i = tid; i < (Cfg::GC * 8 + 512) / 4; i += Cfg::NT) z[i] = 0u;
-  }
+  // ---- prologue: first tiles, codebook rows, scores, entries; behind the requests: the accumulators are zeroed
   issue_tile_all(0, 0, 0);
   wide_lut<BITS>(a, dl, t0, Cfg::lut_off(0), wave, t0 <= fast_end, f_lut);
   wide_p<BITS>(psrc, a, dl, t0, h0, Cfg::p_off(0), wave);
@@ -397,6 +402,10 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
   issue_entry_round(0, t0);
   issue_entry_round(1, t0);
   if constexpr (NU == 2) issue_tile_all(0, 1, 1);          // (the last T_OPS operations: the loop's first wait leaves them in flight)
+  {
+    uint4 *z = reinterpret_cast<uint4 *>(smem + Cfg::ACC_OFF);
+    for (int i = tid; i < (Cfg::GC * 8 + 512) / 16; i += Cfg::NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   load_mz();                                               // (behind the first requests)
   if constexpr (NU == 2) vm_wait<Cfg::T_OPS>(); else vm_wait<0>();
   __syncthreads();
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
       const int r = ul * WORDS + wi, rot = (r >> Cfg::SH) & (Cfg::QR - 1);
       taddr[qq][wi] = (uint32_t)(r * Cfg::ROWB + (((sl * Cfg::QPL + qq + rot) & (Cfg::QR - 1)) << 4));
     }
-  const uint32_t paddr = (uint32_t)(((ul / Cfg::UPH) * CT + sl * Cfg::QPL * 4) * 4);   // (+ u * SU / UPH * CT * 4 per sub-stage)
+  const uint32_t paddr = (uint32_t)(Cfg::p_byte(ul / Cfg::UPH, sl * Cfg::QPL * 4));     // (+ the sub-stage's heads, an immediate)
 
   int slot = 0;       // ring slot of the sub-stage being decoded
   int pcur = 0;       // p buffer of the chunk being decoded
@@ -475,16 +484,15 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
     constexpr std::integral_constant<int, 3> K3{};
     if constexpr (U == 0) issue_chunk_extras(cnx, 1 - LP, FUSED ? (pcur + 2) % 3 : (pcur + 1) % 3);
     if (!FUSED && U == 0 && t1 - c0 < CT) {            // ragged last chunk: zero the probabilities past the end once
-      float *pb = reinterpret_cast<float *>(smem + Cfg::p_off(0)) + pcur * (Cfg::P_B / 4);
       const int rem = (int)(t1 - c0);
-      for (int i = tid; i < Cfg::HW * CT; i += Cfg::NT)
-        if (i % CT >= rem) pb[i] = 0.f;
+      if (tid % CT >= rem) *reinterpret_cast<float *>(smem + Cfg::p_off(0) + pcur * Cfg::P_B + p_elem) = 0.f;
       __syncthreads();
     }
     KVQ_W_STAMP(2);
     constexpr int S0 = Cfg::tile_off(0);
     constexpr int L0 = Cfg::lut_off(LP);
-    constexpr int P0 = Cfg::p_off(0) + U * (Cfg::SU / Cfg::UPH) * CT * 4;
+    static_assert((Cfg::SU / Cfg::UPH) % 2 == 0, "a sub-stage's heads are whole DMA pieces");
+    constexpr int P0 = Cfg::p_off(0) + U * (Cfg::SU / Cfg::UPH / 2) * Cfg::P_PIECE;
     constexpr int TS = Cfg::SLOTS * N * 4;              // bytes between the rows of consecutive tokens of a slot
     const uint32_t tb = (uint32_t)(slot * Cfg::TILE_B);
     const uint32_t paddr_c = paddr + (uint32_t)(pcur * Cfg::P_B);

@@ -352,6 +352,13 @@ def test_token_sharded_attention_with_sink_tokens(bits, S, split, sinks):
         torch.cuda.synchronize()
         scale_o = ref.abs().max().item() + 1e-6
         assert (out - ref).abs().max().item() <= 2e-3 * scale_o, (step, (out - ref).abs().max().item() / scale_o)
+    # a cache that COUNTS sink tokens must be handed them: no silent drop from the softmax
+    q = torch.randn(H, HD, generator=g).half().to(dev)
+    with pytest.raises(ValueError, match="sink"):
+        shard_attention(full[0], full[1], q, pos_base=sinks)
+    with pytest.raises(ValueError, match="sink"):
+        shard_attention(full[0], full[1], q, pos_base=sinks, k_sink=k_sink[:, :, :sinks - 1].contiguous(),
+                        v_sink=v_sink[:, :sinks - 1].contiguous())
 
 
 @pytest.mark.parametrize("bits,sinks,L0", [(4, 0, 40), (3, 5, 300), (2, 0, 40)])

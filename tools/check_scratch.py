@@ -13,14 +13,13 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LLVM = "/opt/rocm/lib/llvm/bin"
+LLVM = os.environ.get("KVQ_LLVM_BIN", os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin"))
+ARCH = os.environ.get("KVQ_ARCH", "gfx950")
 
 # (regex on the demangled-ish kernel name, why scratch is tolerated there)
 ALLOWED = [
     (r"score_k_kernelILi\dELb1ELi8ELb0ELb0ELb0E", "row-layout sparse score kernel of the LEGACY quant_cuda entry points "
                                                   "(decode_kv reads the token-contiguous mirror): 3-5 VGPRs outside the head loop"),
-    (r"mix_v_kernelILi\dELb0E", "p.V with probabilities from memory (legacy kvq_mix_v; decode_kv runs the fused-softmax "
-                                "instantiation): spills around the two outlier-phase orders, none in the chunk loop"),
     (r"fused_decode_kernelILi2E", "fused attend at 2 bit (opt-in route, never a default)"),
 ]
 
@@ -33,7 +32,7 @@ def kernels_of(obj):
         if not os.path.exists(fat) or os.path.getsize(fat) == 0:
             return []
         subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co],
+                               "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH, "--input=" + fat, "--output=" + co],
                               stderr=subprocess.DEVNULL)
         notes = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", co]).decode()
     out, cur = [], {}
@@ -72,6 +71,10 @@ def check(verbose=False):
 
 
 def main():
+    # another ROCm layout / no LLVM tools: nothing to read the code objects with -- say so instead of failing the build
+    if not all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        print("0 kernels checked: LLVM tools not found under %s (set KVQ_LLVM_BIN); scratch check SKIPPED" % LLVM)
+        return 0
     n, problems, tolerated = check("-v" in sys.argv)
     print("%d kernels, %d with scratch in a default path, %d tolerated" % (n, len(problems), len(tolerated)))
     for t in tolerated:

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-fp16-baseline --no-full-model > gpurun_out/${tag}_bench_profiled.json 2> /tmp/prof_$tag.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-fp16-baseline --no-full-model --no-configs > gpurun_out/${tag}_bench_profiled.json 2> /tmp/prof_$tag.log
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 python - "$f" gpurun_out/${tag}_kernel_stats.csv <<'PY'
 import csv, re, sys
