@@ -570,9 +570,12 @@ FUSE_SOFTMAX_UP_TO = int(os.environ.get("KVQ_FUSE_SOFTMAX_UP_TO", str(1 << 62)))
 # the score / p.V kernel pair.  Measured (profiles/r04_fused_decode.txt): slower at 32K (one tile per workgroup leaves
 # half the chip idle), equal at 128K, 3 % slower at 256K, 3.7 % FASTER at 1M (several generations of workgroups: K phases
 # overlap V phases; same box at 1M: nuq4 11.08 -> 10.72 ms/step, but nuq3 + sinks 10.87 -> 11.02 and nuq2 9.28 -> 9.81)
-# -> the default at 4 bit from FUSED_ATTEND_FROM cached tokens on.  KVQ_FUSED_ATTEND=1 / 0 forces it on / off.
+# -> rounds 4 - 5: the default at 4 bit from 512K cached tokens on.  Round 6: the kernel PAIR wins at every length again --
+# its p.V is the one-workgroup-per-CU kernel with the outlier entries inside the loop (kvq_mix_v_wide.hip); same box,
+# profiles/r06_k_misc.txt: 1M 10.70 -> 9.86 ms/step (8 layers), 512K 10.86 -> 9.98, 256K 5.71 -> 5.22 -- so the fused kernel is
+# opt-in only: KVQ_FUSED_ATTEND=1 forces it on (0: off), KVQ_FUSED_ATTEND_FROM=<tokens> turns it on from a length.
 FUSED_ATTEND = {"1": True, "0": False}.get(os.environ.get("KVQ_FUSED_ATTEND", ""), None)
-FUSED_ATTEND_FROM = int(os.environ.get("KVQ_FUSED_ATTEND_FROM", str(512 * 1024)))
+FUSED_ATTEND_FROM = int(os.environ.get("KVQ_FUSED_ATTEND_FROM", str(1 << 62)))
 
 
 def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):

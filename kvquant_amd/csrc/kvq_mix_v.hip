@@ -46,7 +46,8 @@
 #define KVQ_V_WAVES 4           // waves per SIMD the register allocation aims at
 #define KVQ_V_MERGE_PARTS 256   // fused softmax: up to this many score tiles (64K tokens) the p.V workgroups merge the partials themselves
 #ifndef KVQ_V_WIDE_FROM
-#define KVQ_V_WIDE_FROM 12288   // cached tokens from which the 1024-lane geometry (kvq_mix_v_wide.hip) takes a decode step's p.V
+#define KVQ_V_WIDE_FROM 6144    // cached tokens from which the 1024-lane geometry (kvq_mix_v_wide.hip) takes a decode step's p.V
+                                // (same box, profiles/r06_k_misc.txt: 4K 1.757 vs 1.794 ms/step for the wide one, 8K 1.955 vs 1.92, 12K 1.99 vs 1.90)
 #endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24             // outlier phase: entries per lane and token block (one round of loads)

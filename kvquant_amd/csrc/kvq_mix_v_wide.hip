@@ -35,6 +35,9 @@
 #ifndef KVQ_W_BURST
 #define KVQ_W_BURST 0     // 1: the next tile's pieces in one burst behind the barrier instead of a piece per quad
 #endif
+#ifndef KVQ_W_NT
+#define KVQ_W_NT 0        // 1: the tile rows with the non-temporal load policy
+#endif
 #ifndef KVQ_W_PRIO
 #define KVQ_W_PRIO 0      // 1: wave priority = token slot (the youngest wave of a SIMD highest), 2: the reverse
 #endif
@@ -133,7 +136,11 @@ __device__ __forceinline__ void wide_tile_piece(const MixArgs &a, const DmaLane 
     if (r >= n_rows_valid) r = n_rows_valid - 1;
     voff = ((uint32_t)r * (uint32_t)a.max_len + toff) * 4u;
   }
+#if KVQ_W_NT
+  dma16_nt(a.mat + (int64_t)row0 * a.max_len + c0, voff, dst + (wave + K * Cfg::NW) * 1024);
+#else
   dma16(a.mat + (int64_t)row0 * a.max_len + c0, voff, dst + (wave + K * Cfg::NW) * 1024);
+#endif
 }
 // codebook rows of chunk c0 -> LDS `dst` (waves below LUT_LANES / 64; clamped to the rows that exist)
 template <int BITS>

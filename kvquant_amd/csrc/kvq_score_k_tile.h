@@ -11,6 +11,9 @@
 #ifndef KVQ_TRACE
 #define KVQ_TRACE 0     // development: per-phase s_memtime stamps of the head loop (tools/dbg/trace_k.py)
 #endif
+#ifndef KVQ_QL_PAIR
+#define KVQ_QL_PAIR 1   // 0: q of the outlier step as two ds_read_b32 (round 5; A/B runs)
+#endif
 // (the experiment switches of rounds 2-3 -- look-up software pipeline, woven outlier step, wave priorities, outlier
 //  entries after the head loop, a third table buffer -- were measured neutral or slower and are gone; DESIGN.md 3 keeps
 //  the numbers)
@@ -287,7 +290,12 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   auto theta_of = [&](int j) { return __shfl(th_reg, j); };
   if constexpr (SPARSE) {
     for (int i = tid; i < T * SCS; i += NT) sc[i] = 0.f;
-    for (int i = tid; i < nh * kHeadDim; i += NT) ql[i] = qb[h0 * kHeadDim + i];
+    // q of the group's heads, the two channels of a rotation pair adjacent -- (q[j], q[j + 64]) -- so that an outlier entry
+    // reads both with ONE ds_read_b64 (the entries' channels are data: these reads are where the kernel's bank conflicts are)
+    for (int i = tid; i < nh * kHeadDim; i += NT) {
+      const int c = i & (kHeadDim - 1);
+      ql[KVQ_QL_PAIR ? (i - c) + ((c & 63) << 1) + (c >> 6) : i] = qb[h0 * kHeadDim + i];
+    }
   }
 
   // packed words (role r: channel groups r and 2+r) of PF heads rotate through PF register sets
@@ -357,8 +365,14 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
     float sn, c;
     sincos_rev(ang, sn, c);
     const int hq = use ? hh : 0;
+#if KVQ_QL_PAIR
+    const f32x2 qp = *reinterpret_cast<const f32x2 *>(ql + hq * kHeadDim + ((ch & 63) << 1));
+    const float q1 = (ch < 64) ? qp.x : qp.y;
+    const float q2 = (ch < 64) ? qp.y : qp.x;
+#else
     const float q1 = ql[hq * kHeadDim + ch];
-    const float q2 = ql[hq * kHeadDim + ((ch + 64) & 127)];
+    const float q2 = ql[hq * kHeadDim + (ch ^ 64)];
+#endif
     const float sg = (ch < 64) ? sn : -sn;
     float sum = use ? val * fmaf(c, q1, sg * q2) : 0.f;
     // run key = (token, TRUE head): a zeroed or foreign-group entry keeps its own head, it just carries 0
@@ -446,8 +460,14 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
     float sn, c;
     sincos_rev(ang, sn, c);
     const int hq = use ? hhE : 0;
+#if KVQ_QL_PAIR
+    const f32x2 qp = *reinterpret_cast<const f32x2 *>(ql + hq * kHeadDim + ((ch & 63) << 1));
+    const float q1 = (ch < 64) ? qp.x : qp.y;
+    const float q2 = (ch < 64) ? qp.y : qp.x;
+#else
     const float q1 = ql[hq * kHeadDim + ch];
     const float q2 = ql[hq * kHeadDim + (ch ^ 64)];
+#endif
     const float sg = (ch < 64) ? sn : -sn;
     float x = use ? val * fmaf(c, q1, sg * q2) : 0.f;
     const int hk = use ? hhE : (-1 - role);

@@ -46,7 +46,9 @@ PPL_CASES = [
     # kw, bar vs simd, bar vs sim, bar vs rule
     (dict(bits=4), NORTH_STAR, 5e-3, NORTH_STAR),
     (dict(bits=4, n_prompt=1024), NORTH_STAR, 1e-2, NORTH_STAR),
-    (dict(bits=3, first_few_fp16=5), 5e-3, 1e-2, 3e-3),
+    # (vs the deployment rule: five draws -- profiles/r05_b_ppl_delta.jsonl +1.7e-3 / -1.5e-5, r05_z +1.3e-4,
+    #  profiles/r06_i_ppl_cfg3.jsonl +3.0e-5 / +6.3e-4 / -3.1e-5 -- both signs, largest 1.7e-3: bar = 1.5 x that)
+    (dict(bits=3, first_few_fp16=5), 5e-3, 1e-2, 2.5e-3),
     (dict(bits=2, norm=True), NORTH_STAR, 1e-2, NORTH_STAR),
 ]
 
