@@ -63,6 +63,10 @@ extern "C" {
  *        pair-sum tables live behind the fp32 ones);  (d) kvq_score_k_tables takes the shard's fp16 sink tokens, kvq_softmax_stats their
  *        scores, kvq_extract_heads the Q-Norm rows;  (e) new entries: kvq_score_k_prepared_softmax_ex, kvq_decode_step_route,
  *        kvq_append_kv_fused, kvq_attend_step, kvq_head_shard_step.
+ *   401  round 6: no entry point added, removed or re-typed.  Behaviour: kvq_mix_v / kvq_mix_v_softmax (and kvq_decode_step
+ *        through them) run the one-workgroup-per-CU kernel (kvq_mix_v_wide.hip) for q_len = 1 from 6144 cached tokens on --
+ *        same arguments, same workspace size, the outlier sums are still exact (64-bit fixed point) and order independent;
+ *        kvq_head_shard_step validates every argument before its first launch.
  *        A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
 #define KVQ_ABI_MAJOR 4
 KVQ_API int kvq_version(void);
