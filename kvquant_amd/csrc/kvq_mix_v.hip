@@ -49,6 +49,11 @@
 #define KVQ_V_WIDE_FROM 6144    // cached tokens from which the 1024-lane geometry (kvq_mix_v_wide.hip) takes a decode step's p.V
                                 // (same box, profiles/r06_k_misc.txt: 4K 1.757 vs 1.794 ms/step for the wide one, 8K 1.955 vs 1.92, 12K 1.99 vs 1.90)
 #endif
+#ifndef KVQ_W_MERGE_PARTS
+#define KVQ_W_MERGE_PARTS 256   // wide p.V: up to this many score tiles (64K tokens) the workgroups merge the softmax partials themselves
+                                // (1024 measured: the merge in every workgroup's prologue costs what the launch costs -- 128K 5.56 vs 5.67 ms/step,
+                                //  profiles/r06_n_merge.txt)
+#endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24             // outlier phase: entries per lane and token block (one round of loads)
 #endif
@@ -1073,8 +1078,14 @@ static int launch_mix(MixArgs a, float *mul, int accumulate, hipStream_t st, con
   if (a.L >= wide_from() && mix_wide_ok(BITS, a)) {
     // (the workspace is the 512-lane plan's: the wide plan writes fewer slabs; the (max, normaliser) pairs keep their place)
     const float *mzp = nullptr;
-    // the merge kernel: many score tiles, or sink tokens (whose probabilities and outputs it writes)
-    if (fs && (fs->n_sink > 0 || fs->n_parts > kMergeInKernelParts)) {
+    // the merge kernel: sink tokens (whose probabilities and outputs it writes), or very many score tiles.  Otherwise the 256
+    // workgroups merge the partials themselves, 32 lanes per head behind their first requests (KVQ_W_MERGE_PARTS tiles =
+    // 256K tokens: 16 loads per lane at 128K, from the L2 -- 32 MB of reads per launch against a 4.8 us launch)
+    static const int wide_merge_parts = [] {
+      const char *e = getenv("KVQ_W_MERGE_PARTS_RT");          // (A/B runs)
+      return e ? atoi(e) : KVQ_W_MERGE_PARTS;
+    }();
+    if (fs && (fs->n_sink > 0 || fs->n_parts > wide_merge_parts)) {
       float *mz = a.partial + (size_t)pl.n_ranges * (a.q_len == 1 ? pl.groups : a.q_len) * a.H * kHeadDim;
       softmax_merge_kernel<<<a.H, 256, 0, st>>>(fs->parts, fs->n_parts, fs->sink, fs->sink_probs, fs->n_sink, mz, fs->v_sink, mul);
       int rc0 = check_launch();
