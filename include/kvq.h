@@ -319,7 +319,13 @@ KVQ_API int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mu
  * agree with the fp32 tables to ~1e-4 of a row's largest score (contract: 1e-3; the reference rounds the scores
  * themselves to fp16, modeling_llama.py:873).  128K nuq3: q.K^T 80.4 us (exact fp32 tables) -> 70.6 us
  * (DESIGN.md 3.6b); scores within 4e-4 of the reference's, attention outputs within 4e-3 (1.4e-3 .. 1.8e-3 measured). */
+/* KVQ_SCORE_F32_PAIR_TABLES (round 6; 3 bit, token-contiguous mirror, L >= 16384; ignored elsewhere): the same pair sums in
+ * FP32 (64 entries x 8 B per pair, 32 KB per head, in the place of the fp16 image: a workspace holds one of the two) --
+ * exact arithmetic, one ds_read_b64 + one v_pk_fma_f32 per two codes, one 1024-lane workgroup of 512 tokens per CU.
+ * Opt-in (kvquant_amd: KVQ_SCORE_F32_PAIR=1): equal to the per-channel tables at 128K, 3 % faster at 1M, slower at 32K
+ * (profiles/r06_p_pair32_ab.txt). */
 #define KVQ_SCORE_F16_PAIR_TABLES 1
+#define KVQ_SCORE_F32_PAIR_TABLES 2
 KVQ_API int kvq_score_k_prepared_softmax_ex(int bits, const int32_t *mat, float *mul,
                          const float *lut, int H, int hd, int64_t L, int64_t max_len,
                          float rope_theta, int pos_offset, const float *outliers,
@@ -406,6 +412,8 @@ typedef struct kvq_layer {
 } kvq_layer;
 /* kvq_layer.flags: 3-bit caches score through the fp16 pair-sum tables (KVQ_SCORE_F16_PAIR_TABLES above) */
 #define KVQ_LAYER_SCORE_F16_PAIR 1
+/* ... through the exact fp32 pair-sum tables (KVQ_SCORE_F32_PAIR_TABLES above; wins over the fp16 flag) */
+#define KVQ_LAYER_SCORE_F32_PAIR 2
 
 /* One decode token through one layer: K / V fused appends at column kcol (= vcol) + query tables, q.K^T with RoPE +
  * outliers + first softmax pass, softmax, p.V + outliers, slab reduce -- the launches of kvq_decode_prologue,

@@ -107,6 +107,7 @@ SIGNATURES = {
 _lib = None
 ABI_MAJOR = 4      # include/kvq.h: KVQ_ABI_MAJOR
 LAYER_SCORE_F16_PAIR = 1   # kvq_layer.flags
+LAYER_SCORE_F32_PAIR = 2
 SCORE_F16_PAIR_TABLES = 1  # kvq_score_k_prepared_softmax_ex flags
 
 

@@ -114,6 +114,12 @@ class QuantK(nn.Module):
         # ~0.4 ulp of the fp16 value the reference rounds every score to (ML:873), so four scores in ten land on the
         # neighbouring fp16 value and the attention OUTPUT moves by 1.4e-3 .. 1.8e-3 (held to 4e-3 by tests/test_atsize_gpu.py).  Default False:
         # the fp32 tables, whose scores round like the reference's.  Env KVQ_SCORE_F16=1 turns it on for every 3-bit cache.
+        # 3 bit, decode through kvq_decode_step, >= 16K cached tokens: the EXACT fp32 pair-sum tables (round 6; include/kvq.h
+        # KVQ_SCORE_F32_PAIR_TABLES) -- one look-up and one packed FMA per two codes, the same fp32 arithmetic in another
+        # order, one 1024-lane score workgroup per CU.  Opt-in (KVQ_SCORE_F32_PAIR=1): measured EQUAL to the per-channel
+        # tables at 128K (81.7 vs 81.9 us), slower at 32K (42.2 vs 39.4), 3 % faster at 1M (profiles/r06_p_pair32_ab.txt):
+        # the look-ups are not what holds the 3-bit kernel, and one workgroup per CU loses the overlap of two.
+        self.score_f32_pair = bits == 3 and os.environ.get("KVQ_SCORE_F32_PAIR", "0") == "1"
         self.score_f16_pair = bits == 3 and os.environ.get("KVQ_SCORE_F16", "0") == "1"
         if self.score_f16_pair and not getattr(QuantK, "_f16_pair_logged", False):
             QuantK._f16_pair_logged = True
@@ -613,7 +619,7 @@ def decode_kv(kc, vc, q, k, v, sink_scores=None, k_sink=None, v_sink=None):
         # the whole launch sequence from one library call (kvq_decode_step): the five Python / ctypes round trips of
         # the path below cost ~78 us of host time per layer, as much as the GPU needs for a 4K-token cache
         key = (id(vc), getattr(vc, "_tables_version", 0), vc.reference_tie_quirk, vc.norm, kc.norm, kc.compact, vc.compact,
-               kc.score_f16_pair)
+               kc.score_f16_pair, getattr(kc, "score_f32_pair", False))
         cached = getattr(kc, "_step_layer", None)
         if cached is None or cached[0] != key:
             cached = (key,) + ops.make_layer(kc, vc, table, lut_off)

@@ -49,6 +49,18 @@ static StepPlan plan_step(int bits, int H, int hd, int64_t L) {
 static thread_local hipEvent_t *step_events = nullptr;
 
 static thread_local bool mark2_pending = false;
+// which pair-sum image of the 3-bit score tables a layer's step builds and reads (kvq.h: KVQ_LAYER_SCORE_*): the fp32 one from
+// 16K cached tokens on (below, the per-channel tables, which are always built), else the fp16 one if asked for
+static inline int pair_mode_of(const kvq_layer *ly, int64_t L) {
+  if (ly->bits != 3) return 0;
+  if ((ly->flags & KVQ_LAYER_SCORE_F32_PAIR) && L >= 16384 && ly->kidx_t != nullptr) return 2;
+  return (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) ? 1 : 0;
+}
+static inline int score_flags_of(const kvq_layer *ly, int64_t L) {
+  const int m = pair_mode_of(ly, L);
+  return m == 2 ? KVQ_SCORE_F32_PAIR_TABLES : (m == 1 ? KVQ_SCORE_F16_PAIR_TABLES : 0);
+}
+
 static thread_local int last_route = -1;      // which launch sequence the last kvq_decode_step on this thread took
 static thread_local int step_fused_mark = 0;
 static void record(int i, hipStream_t st) {
@@ -143,7 +155,7 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
                            ly->vmat, ly->vlut_rows, ly->vlut_sorted, v, ly->voutliers, ly->vidx, vcol, q,
                            acts_are_half, ly->thr_k, H, hd, ly->max_len, ly->koutliers_t, ly->kidx_t, ly->klut_ends,
                            ly->klut_score, ly->vnorm, sinks, ws, p.score_ws,
-                           (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) != 0, stream);
+                           pair_mode_of(ly, L), stream);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   struct Clear { ~Clear() { step_events = nullptr; } } clear_events_on_exit;
@@ -166,7 +178,7 @@ int kvq_decode_step(const kvq_layer *ly, int64_t kcol, int64_t vcol, const void 
   rc = kvq_score_k_prepared_softmax_ex(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta,
                                        ly->pos_offset, ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws,
                                        p.score_ws, inv, parts, p.n_parts,
-                                       (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) ? KVQ_SCORE_F16_PAIR_TABLES : 0, stream);
+                                       score_flags_of(ly, L), stream);
   record(1, st);
   if (rc) return rc;
   return step_tail(ly, sinks, v_sink, sink_probs, out, fuse_softmax, scores, probs, parts, p.n_parts, ws, p, L, n_out, n_sink, inv, st);
@@ -203,7 +215,7 @@ static int attend_step(const kvq_layer *ly, int64_t L, const void *q, int acts_a
   rc = kvq_score_k_prepared_softmax_ex(bits, ly->kmat, scores, ktab, H, hd, L, ly->max_len, ly->rope_theta, ly->pos_offset,
                                        ly->koutliers, ly->kidx, n_out, ly->koutliers_t, ly->kidx_t, ws, p.score_ws, inv,
                                        parts, p.n_parts,
-                                       (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) ? KVQ_SCORE_F16_PAIR_TABLES : 0, stream);
+                                       (ly->flags & KVQ_LAYER_SCORE_F16_PAIR) ? KVQ_SCORE_F16_PAIR_TABLES : 0, stream);   // (tables built by the caller: kvq_score_k_tables / the extract, which know the fp16 image only)
   record(1, st);
   if (rc) return rc;
   return step_tail(ly, sinks, v_sink, sink_probs, out, fuse_softmax, scores, probs, parts, p.n_parts, ws, p, L, n_out, n_sink, inv, st);

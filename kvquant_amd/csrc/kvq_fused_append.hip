@@ -471,6 +471,7 @@ struct PrologueArgs {
   unsigned char *tab;      // score workspace: tables, then q as fp32, then (3 bit) the pair-sum images
   float *q32;
   unsigned char *pair_tab;
+  int pair_mode;           // 0: none, 1: fp16 pair sums (KTabPair3), 2: fp32 pair sums (KTabPair32)
   int H;
   // fp16 attention-sink tokens (optional): scaled scores q . k_sink of head h by the head's table workgroup -- the
   // reference's torch.matmul(query_states, key_states_fp16) / sqrt(d) (ML:1950-1962): fp32 accumulation, the fp16
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(kSelThreads) void decode_prologue_kernel(PrologueAr
   } else {
     const int h = (int)blockIdx.x - 2;
     quantize_head<BITS>(P.k, h);
-    lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.pair_tab, P.H, h, 0);
+    lutq_prep_head<BITS>(P.klut, P.q, P.q_is_half, P.tab, P.q32, P.pair_tab, P.H, h, 0, P.pair_mode);
     if (P.k_sink != nullptr) {
       // scores of the fp16 sink tokens: one wave per sink token, two channels per lane (one thread per token walked the
       // 128 channels alone -- 128 dependent loads, which made these workgroups the prologue's critical path: 19.4 us
@@ -703,7 +704,7 @@ int kvq_pack_v_fused(int bits, int32_t *mat, float *lut_rows, const float *lut_s
 }  // extern "C"
 
 namespace kvq {
-// kvq_decode_prologue with the choice of score images: `pair_images` = also the 3-bit fp16 pair-sum image (KTabPair3;
+// kvq_decode_prologue with the choice of score images: `pair_images` = 1: also the 3-bit fp16 pair-sum image (KTabPair3;
 // 4096 gathered entries per head -- only the layers that score with it pay for it)
 int decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klut_off, const void *k,
                     const float *lo, const float *hi, float *koutliers, int32_t *kidx, int64_t kcol,
@@ -712,7 +713,7 @@ int decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klu
                     int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
                     const float *klut_ends, const float *klut_score, const kvq_vopts *vnorm,
                     const kvq_sinks *sinks, void *score_workspace, size_t score_workspace_bytes,
-                    bool pair_images, void *stream) {
+                    int pair_images, void *stream) {
   if (hd != kHeadDim || !q || !score_workspace || bits < 2 || bits > 4) return KVQ_EINVAL;
   if (sinks != nullptr && sinks->n_sink > 0 && (!sinks->k_sink || !sinks->sink_scores || sinks->n_sink > 1024))
     return KVQ_EINVAL;
@@ -737,6 +738,7 @@ int decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klu
   const size_t tabb = bits == 4 ? KTab<4>::BUF_B : (bits == 3 ? KTab<3>::BUF_B : KTab<2>::BUF_B);
   P.q32 = reinterpret_cast<float *>(P.tab + (size_t)H * tabb);
   P.pair_tab = (bits == 3 && pair_images) ? P.tab + ktab_pair_offset<3>(1, H) : nullptr;
+  P.pair_mode = pair_images;
   P.H = H;
   P.k_sink = nullptr;
   P.sink_scores = nullptr;
@@ -803,6 +805,7 @@ int kvq_append_kv_fused(const kvq_layer *ly, int64_t col, const void *k, const v
   P.tab = nullptr;
   P.q32 = nullptr;
   P.pair_tab = nullptr;
+  P.pair_mode = 0;
   P.H = ly->H;
   P.k_sink = nullptr;
   P.sink_scores = nullptr;

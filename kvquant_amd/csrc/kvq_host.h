@@ -28,7 +28,7 @@ int decode_prologue(int bits, int32_t *kmat, const float *klut, const float *klu
                     const float *vlut_sorted, const void *v, float *voutliers, int32_t *vidx, int64_t vcol, const void *q,
                     int acts_are_half, int thr_k, int H, int hd, int64_t max_len, float *koutliers_t, int32_t *kidx_t,
                     const float *klut_ends, const float *klut_score, const kvq_vopts *vnorm, const kvq_sinks *sinks,
-                    void *score_workspace, size_t score_workspace_bytes, bool pair_images, void *stream);
+                    void *score_workspace, size_t score_workspace_bytes, int pair_images, void *stream);
 
 // kvq_mix_v.hip: the launches around the p.V kernels (shared with tools/experiments/kvq_mix_va.hip)
 int launch_mix_reduce(const float *partial, float *mul, int n_ranges, int q_len, int C, int accumulate, hipStream_t st);

@@ -34,6 +34,15 @@ struct KTabPair3 {
   static constexpr int PAIR_B = 64 * 4;             // one (pair, role)
   static constexpr int BUF_B = 32 * 2 * PAIR_B;     // one head: 16 KB
 };
+// 3 bit: the same pair sums in fp32 (round 6) -- EXACT arithmetic (a sum of two fp32 products, as the per-channel path forms it,
+// in another order), one ds_read_b64 + one v_pk_fma_f32 per TWO codes.  64 entries x 8 B per (pair, role) = 32 KB per head: two
+// table buffers + the score tile of 512 tokens need a 1024-lane workgroup, one per CU (score_k_kernel<3, ..., NWAVES = 16, PAIR = 2>).
+//   P32[((i*2 + r)*64 + (c_lo | c_hi << 3))] = (a*q[k_lo] + b*q[k_hi],  a*q[k_hi] - b*q[k_lo])
+// The image lives where the fp16 one does (a layer scores through one of them): the region is sized for the larger.
+struct KTabPair32 {
+  static constexpr int PAIR_B = 64 * 8;             // one (pair, role)
+  static constexpr int BUF_B = 32 * 2 * PAIR_B;     // one head: 32 KB
+};
 // does this width keep a pair-sum image next to the fp32 one?
 template <int BITS>
 struct KTabHasPair { static constexpr bool value = BITS == 3; };
@@ -50,7 +59,7 @@ __host__ __device__ __forceinline__ size_t ktab_pair_offset(int q_len, int H) {
 }
 template <int BITS>
 __host__ __device__ __forceinline__ size_t ktab_total_bytes(int q_len, int H) {
-  return ktab_pair_offset<BITS>(q_len, H) + (KTabHasPair<BITS>::value ? (size_t)q_len * H * KTabPair3::BUF_B : 0);
+  return ktab_pair_offset<BITS>(q_len, H) + (KTabHasPair<BITS>::value ? (size_t)q_len * H * KTabPair32::BUF_B : 0);
 }
 
 // builds the image of head h / query row b in global memory (L2-resident: H*16 KB) and the fp32 copy
@@ -59,7 +68,7 @@ template <int BITS>
 __device__ __forceinline__ void lutq_prep_head(const float *__restrict__ lut, const void *__restrict__ q,
                                                int q_is_half, unsigned char *__restrict__ tab,
                                                float *__restrict__ q32, unsigned char *__restrict__ pair_tab, int H,
-                                               int h, int b) {
+                                               int h, int b, int pair_mode = 1) {
   constexpr int N = Fmt<BITS>::kN;
   const float *lh = lut + (int64_t)h * kHeadDim * N;
   const int64_t qoff = ((int64_t)b * H + h) * kHeadDim;
@@ -79,7 +88,20 @@ __device__ __forceinline__ void lutq_prep_head(const float *__restrict__ lut, co
   }
   if constexpr (KTabHasPair<BITS>::value) {
     // the pair-sum image (KTabPair3): 4096 entries per head
-    if (pair_tab == nullptr) return;
+    if (pair_tab == nullptr || pair_mode == 0) return;
+    if (pair_mode == 2) {       // fp32 pair sums (KTabPair32)
+      unsigned char *pdst = pair_tab + ((int64_t)b * H + h) * KTabPair32::BUF_B;
+      for (int e = threadIdx.x; e < 32 * 2 * 64; e += blockDim.x) {
+        const int idx = e & 63, ir = e >> 6;           // ir = i*2 + r
+        const int i = ir >> 1, r = ir & 1;
+        const int k_lo = 32 * r + i, k_hi = k_lo + 64;
+        const float a = lh[k_lo * N + (idx & 7)], bb = lh[k_hi * N + (idx >> 3)];
+        const float q_lo = ld_act(q, qoff + k_lo, q_is_half), q_hi = ld_act(q, qoff + k_hi, q_is_half);
+        // (products rounded one by one, then added: the per-channel tables hold exactly these products)
+        reinterpret_cast<f32x2 *>(pdst)[e] = f32x2{a * q_lo + bb * q_hi, a * q_hi - bb * q_lo};
+      }
+      return;
+    }
     unsigned char *pdst = pair_tab + ((int64_t)b * H + h) * KTabPair3::BUF_B;
     for (int e = threadIdx.x; e < 32 * 2 * 64; e += blockDim.x) {
       const int idx = e & 63, ir = e >> 6;           // ir = i*2 + r
@@ -98,8 +120,8 @@ template <int BITS>
 __global__ __launch_bounds__(256) void lutq_prep_kernel(const float *__restrict__ lut, const void *__restrict__ q,
                                                         int q_is_half, unsigned char *__restrict__ tab,
                                                         float *__restrict__ q32, unsigned char *__restrict__ pair_tab,
-                                                        int H) {
-  lutq_prep_head<BITS>(lut, q, q_is_half, tab, q32, pair_tab, H, blockIdx.x, blockIdx.y);
+                                                        int H, int pair_mode = 1) {
+  lutq_prep_head<BITS>(lut, q, q_is_half, tab, q32, pair_tab, H, blockIdx.x, blockIdx.y, pair_mode);
 }
 
 }  // namespace kvq

@@ -39,7 +39,10 @@
 #define KVQ_W_NT 0        // 1: the tile rows with the non-temporal load policy
 #endif
 #ifndef KVQ_W_PRIO
-#define KVQ_W_PRIO 0      // 1: wave priority = token slot (the youngest wave of a SIMD highest), 2: the reverse
+#define KVQ_W_PRIO 3      // 0: none, 1: wave priority = token slot (the youngest wave of a SIMD highest), 2: the reverse,
+                          // 3 (default): slot in a sub-stage's first quad, the reverse in its second -- every wave is favoured half of
+                          // the time, the waves of a SIMD reach the barrier together (barrier wait 1815 -> 1073 cycles per chunk; the loop is
+                          // throughput-bound, so the kernel gains little: nuq3 73.3 -> 71.4 us, nuq4 75.3 -> 74.8, profiles/r06_o_prio3.txt)
 #endif
 #ifndef KVQ_W_ABL
 #define KVQ_W_ABL 0       // 1: no outlier evaluation, 2: no look-up loop, 4: no tile DMA (results wrong)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
   }
   const int64_t t1 = (t0 + (int64_t)n_chunks * CT < a.L) ? t0 + (int64_t)n_chunks * CT : a.L;
   if (lds_addr(smem) != 0) __builtin_trap();   // (the instruction immediates below assume the one static LDS array at 0)
-#if KVQ_W_PRIO
+#if KVQ_W_PRIO == 1 || KVQ_W_PRIO == 2
   {
     const int pr = KVQ_W_PRIO == 1 ? sl : 3 - sl;
     if (pr == 1) __builtin_amdgcn_s_setprio(1);
@@ -470,6 +473,15 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
     const bool conv_on = FUSED && c + 1 < n_chunks;
     auto hook = [&](auto QQ, auto K_) {
       constexpr int qq = decltype(QQ)::value, k = decltype(K_)::value;
+#if KVQ_W_PRIO == 3
+      if constexpr (k == 0) {
+        const int pr = (qq & 1) ? 3 - sl : sl;
+        if (pr == 0) __builtin_amdgcn_s_setprio(0);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      }
+#endif
       constexpr int K_ENT = NU == 2 ? 2 : 1;                 // entries: issue at K_ENT, commit at K_ENT + 1
       if constexpr (NU == 1 || U == 0) {
         const bool on = sparse && qq * Cfg::NT + wave * 64 < NE && !(KVQ_W_ABL & 1);        // (this wave has entries in round qq)

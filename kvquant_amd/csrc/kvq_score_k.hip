@@ -47,7 +47,7 @@
 
 namespace kvq {
 
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false, bool PAIR = false>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false, int PAIR = 0>
 __global__ __launch_bounds__(NWAVES * 64, 4)
 void score_k_kernel(ScoreKArgs a) {
   using G = KGeom<BITS, SPARSE, NWAVES, TRANSPOSED, PAIR>;
@@ -75,13 +75,19 @@ void score_k_kernel(ScoreKArgs a) {
     // the scaled scores among themselves, and lane 0 of each head writes the tile's partial.
     if (a.sm_parts != nullptr) {
       __syncthreads();   // a wave wrote only its own tokens' rows
-      constexpr int TPH = NT / 32;
+      // (a partial covers PT = 256 tokens -- the unit kvq_score_k_softmax_parts counts in: the 512-token tile of the 16-wave
+      //  variant writes two, lanes [0, 16) and [16, 32) of a head's 32 taking a half each)
+      constexpr int TPH = NT / 32;                       // lanes per head
+      constexpr int PT = T > 256 ? 256 : T;              // tokens per partial
+      constexpr int NP = T / PT;                         // partials per tile
+      constexpr int LPP = TPH / NP;                      // lanes per partial
       const int hh = tid / TPH, r = tid % TPH;
-      float x[T / TPH];
+      const int half = r / LPP, rr = r % LPP;
+      float x[PT / LPP];
       float m = -INFINITY, sm = 0.f;
 #pragma unroll
-      for (int k = 0; k < T / TPH; k++) {
-        const int j = r + k * TPH;
+      for (int k = 0; k < PT / LPP; k++) {
+        const int j = half * PT + rr + k * LPP;
         x[k] = (j < ntok && hh < nh) ? scaled(sc[j * SCS + ((hh + j) & (SCS - 1))], a.sm_inv) : -INFINITY;
         m = fmaxf(m, x[k]);
       }
@@ -92,17 +98,18 @@ void score_k_kernel(ScoreKArgs a) {
       auto ex = [&](float d) { return __builtin_amdgcn_exp2f(d * kLog2e); };   // d <= 0; 2^-inf = 0
       if (m > -INFINITY) {
 #pragma unroll
-        for (int k = 0; k < T / TPH; k++) sm += ex(x[k] - m);     // 0 for the padding
+        for (int k = 0; k < PT / LPP; k++) sm += ex(x[k] - m);     // 0 for the padding
       }
 #pragma unroll
-      for (int d = TPH / 2; d >= 1; d >>= 1) {
+      for (int d = LPP / 2; d >= 1; d >>= 1) {
         const float mo = __shfl_xor(m, d), so = __shfl_xor(sm, d);
         const float mn = fmaxf(m, mo);
         sm = (mn == -INFINITY) ? 0.f : sm * ex(m - mn) + so * ex(mo - mn);
         m = mn;
       }
-      if (r == 0 && hh < nh) {
-        float *dst = a.sm_parts + ((int64_t)(h0 + hh) * a.sm_nparts + tile_i) * 2;
+      const int part = tile_i * NP + half;
+      if (rr == 0 && hh < nh && part < a.sm_nparts) {
+        float *dst = a.sm_parts + ((int64_t)(h0 + hh) * a.sm_nparts + part) * 2;
         dst[0] = m;
         dst[1] = sm;
       }
@@ -167,7 +174,7 @@ static int pick_groups(int H, int64_t tiles, int q_len, int max_hpg, int slots) 
   return best;
 }
 
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false, bool PAIR = false>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED = false, bool COMPACT = false, int PAIR = 0>
 static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipStream_t st) {
   constexpr int T = NWAVES * 32;
   ScoreKArgs a = a0;
@@ -188,7 +195,8 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   if (a.hpg_tail > a.H) a.hpg_tail = a.H;
   const int tail_blocks = rem ? (a.H + a.hpg_tail - 1) / a.hpg_tail : 0;
   dim3 grid((unsigned)(a.full_blocks + tail_blocks), 1, q_len), block(NWAVES * 64);
-  if (a.sm_parts != nullptr && (!SPARSE || a.sm_nparts != (int)((a.L + T - 1) / T))) return KVQ_EINVAL;
+  constexpr int PT = T > 256 ? 256 : T;        // tokens per softmax partial
+  if (a.sm_parts != nullptr && (!SPARSE || a.sm_nparts != (int)((a.L + PT - 1) / PT))) return KVQ_EINVAL;
   a.rope_theta = rope_theta;
 #if KVQ_TRACE
   a.trace = reinterpret_cast<unsigned long long *>(strtoull(getenv("KVQ_TRACE_PTR") ? getenv("KVQ_TRACE_PTR") : "0", nullptr, 0));
@@ -205,7 +213,8 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
   float *q32 = reinterpret_cast<float *>(tab + (size_t)q_len * a.H * KTab<BITS>::BUF_B);
   if (!tables_ready) {
     lutq_prep_kernel<BITS><<<dim3(a.H, q_len), 256, 0, st>>>(
-        lut, q_in, q_is_half, tab, q32, KTabHasPair<BITS>::value ? tab + ktab_pair_offset<BITS>(q_len, a.H) : nullptr, a.H);
+        lut, q_in, q_is_half, tab, q32, KTabHasPair<BITS>::value ? tab + ktab_pair_offset<BITS>(q_len, a.H) : nullptr, a.H,
+        a.pair == 2 ? 2 : 1);
     int rc = check_launch();
     if (rc) return rc;
   }
@@ -213,13 +222,19 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
   a.tab_pair = KTabHasPair<BITS>::value ? tab + ktab_pair_offset<BITS>(q_len, a.H) : nullptr;
   a.q = q32;   // fp32 copy made by the prep (the sparse phase reads q directly)
   if constexpr (BITS == 3) {
+    // fp32 pair-sum tables (round 6; decode, q_len = 1, mirror formats, >= 16K tokens): exact, half the look-ups, one
+    // 1024-lane workgroup per CU (kvq_ktab.h: KTabPair32); shorter caches take the per-channel tables, which are always built
+    if (a.pair == 2 && q_len == 1 && a.idx_t != nullptr && a.L >= 16384) {
+      return a.out_t == nullptr ? launch_score<3, true, 16, true, true, 2>(a, q_len, theta, st)
+                                : launch_score<3, true, 16, true, false, 2>(a, q_len, theta, st);
+    }
     // fp16 pair-sum tables (decode, q_len = 1, mirror formats): half the look-ups (kvq_ktab.h: KTabPair3)
-    if (a.pair && q_len == 1 && a.idx_t != nullptr) {
+    if (a.pair == 1 && q_len == 1 && a.idx_t != nullptr) {
       if (a.out_t == nullptr)
-        return a.L >= 16384 ? launch_score<3, true, 8, true, true, true>(a, q_len, theta, st)
-                            : launch_score<3, true, 4, true, true, true>(a, q_len, theta, st);
-      return a.L >= 16384 ? launch_score<3, true, 8, true, false, true>(a, q_len, theta, st)
-                          : launch_score<3, true, 4, true, false, true>(a, q_len, theta, st);
+        return a.L >= 16384 ? launch_score<3, true, 8, true, true, 1>(a, q_len, theta, st)
+                            : launch_score<3, true, 4, true, true, 1>(a, q_len, theta, st);
+      return a.L >= 16384 ? launch_score<3, true, 8, true, false, 1>(a, q_len, theta, st)
+                          : launch_score<3, true, 4, true, false, 1>(a, q_len, theta, st);
     }
   }
   // big tiles (8 waves) once there are enough of them, small tiles for short caches
@@ -350,7 +365,7 @@ int kvq_score_k_prepared_softmax_ex(int bits, const int32_t *mat, float *mul, co
   return score_entry(bits, nullptr, 0, 1, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset,
                      outlier_idx_t ? nullptr : outliers, outlier_idx_t ? nullptr : outlier_idx, n_out, 0, workspace,
                      workspace_bytes, stream, softmax_parts, inv_sqrt_hd, n_parts, outliers_t, outlier_idx_t,
-                     (flags & KVQ_SCORE_F16_PAIR_TABLES) ? 1 : 0);
+                     (flags & KVQ_SCORE_F32_PAIR_TABLES) ? 2 : ((flags & KVQ_SCORE_F16_PAIR_TABLES) ? 1 : 0));
 }
 
 }  // extern "C"

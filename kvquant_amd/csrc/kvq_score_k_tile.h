@@ -116,11 +116,12 @@ constexpr int kSparseHpg = 32;   // heads per workgroup cap of the sparse varian
 // COMPACT (implies TRANSPOSED): the mirror holds packed entries -- fp16 residual << 16 | channel, 4 bytes instead of 8 --
 // in idx_t (opt-in format of kvquant_amd's own cache); one load per entry.
 // LDS geometry of a score workgroup (shared with kvq_fused_decode.hip, which runs the same tile body)
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool PAIR = false>
+// PAIR: 0 = one table entry per code, 1 = fp16 pair-sum tables (KTabPair3), 2 = fp32 pair-sum tables (KTabPair32)
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, int PAIR = 0>
 struct KGeom {
   static constexpr int T = NWAVES * 32;
   static constexpr int NT = NWAVES * 64;
-  static constexpr int TAB_B = PAIR ? KTabPair3::BUF_B : KTab<BITS>::BUF_B;
+  static constexpr int TAB_B = PAIR == 2 ? KTabPair32::BUF_B : (PAIR == 1 ? KTabPair3::BUF_B : KTab<BITS>::BUF_B);
   static constexpr int SCS = kSparseHpg;
   static constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
   static constexpr int PF = SPARSE ? 2 : 3;
@@ -142,16 +143,16 @@ struct KTile {
 // (tile_i, h0_i, nh_i): the tile and the head group; score_k_tile below derives them from the block index
 // PAIR (3 bit, implies TRANSPOSED): fp16 pair-sum tables (KTabPair3) -- one ds_read_b32 + one v_dot2_f32_f16 per TWO codes,
 // half2 (cos, sin) per rotation pair (32 instead of 64 trig registers).
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT, bool PAIR = false>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT, int PAIR = 0>
 __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned char *smem, int tile_i, int h0_i, int nh_i) {
   static_assert(!TRANSPOSED || SPARSE, "the transposed mirror is a sparse variant");
   static_assert(!COMPACT || TRANSPOSED, "packed entries live in the mirror");
-  static_assert(!PAIR || (BITS == 3 && TRANSPOSED), "pair-sum tables: 3 bit, decode (mirror) variants");
+  static_assert(PAIR == 0 || (BITS == 3 && TRANSPOSED), "pair-sum tables: 3 bit, decode (mirror) variants");
   constexpr int N = Fmt<BITS>::kN;
   constexpr int WPH = Fmt<BITS>::kWordsPerHead;
   constexpr int T = NWAVES * 32;
   constexpr int NT = NWAVES * 64;
-  constexpr int TAB_B = PAIR ? KTabPair3::BUF_B : KTab<BITS>::BUF_B;
+  constexpr int TAB_B = PAIR == 2 ? KTabPair32::BUF_B : (PAIR == 1 ? KTabPair3::BUF_B : KTab<BITS>::BUF_B);
   constexpr int SCS = kSparseHpg;       // score-tile row stride (token-major; the column is rotated by the
                                         // token so that neither the per-token nor the per-head access conflicts)
   constexpr int SC_B = SPARSE ? T * SCS * 4 : 16;
@@ -423,15 +424,15 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
   }
 
   // RoPE angles of this lane's token for its 32 rotation pairs (KCU:3083, 3122-3123)
-  f32x2 cs[PAIR ? 1 : 32];   // (cos, sin)
-  h16x2 csh[PAIR ? 32 : 1];  // PAIR: the same as half2
+  f32x2 cs[PAIR == 1 ? 1 : 32];   // (cos, sin)
+  h16x2 csh[PAIR == 1 ? 32 : 1];  // PAIR == 1: the same as half2
   const float posf = (float)((int)tc + a.pos_offset);
   static_for<0, 32>([&](auto I) {
     constexpr int i = decltype(I)::value;
     const float ang = theta_of(role * 32 + i) * posf;
     float sn, c;
     sincos_rev(ang, sn, c);
-    if constexpr (PAIR) {
+    if constexpr (PAIR == 1) {
       csh[i] = h16x2{(_Float16)c, (_Float16)sn};
     } else {
       cs[i].x = c;
@@ -548,13 +549,15 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
     //  issues the same operations per head; its results are dropped below)
     float accp[4] = {0.f, 0.f, 0.f, 0.f};          // PAIR: fp32 accumulators of the v_dot2 chain
     if ((wact || JIT) && !(KVQ_ABL & 64)) {
-    if constexpr (PAIR) {
+    if constexpr (PAIR != 0) {
       // The 3-bit fields of the two 96-bit streams (channels 32r.. in wlo, 64+32r.. in whi) are merged pairwise into 6-bit
       // indices c_lo | c_hi << 3, planted at bits 2 + 6k of a register with the role bit above every second one, so that a
       // single cut of 9 bits is the variable part of the look-up address, index * 4 + role * 256 (KTabPair3).  Word w holds
       // fields g = 0..9 of the stream from bit w on (pair i = 11w + g); the two straddling fields, i = 10 and 21, are
-      // assembled from two words.
+      // assembled from two words.  PAIR == 2 (fp32 sums, KTabPair32): the same index, entries of 8 bytes -- the cut shifted left
+      // by one is index * 8 + role * 512 --, one ds_read_b64 and one packed FMA against the lane's fp32 (cos, sin).
       const unsigned char *tp = lutq + buf * TAB_B;
+      constexpr int PB = PAIR == 2 ? KTabPair32::PAIR_B : KTabPair3::PAIR_B;
       static_for<0, 3>([&](auto WI) {
         constexpr int w = decltype(WI)::value;
         static_for<0, 2>([&](auto PI) {
@@ -573,17 +576,31 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
           asm("v_bfe_u32 %0, %1, 12, 9" : "=v"(ad[2]) : "v"(xa));
           asm("v_bfe_u32 %0, %1, 18, 9" : "=v"(ad[3]) : "v"(xb));
           asm("v_alignbit_b32 %0, %1, %2, 24" : "=v"(ad[4]) : "v"(role_u), "v"(xa));
-          h16x2 v[5];
-          static_for<0, 5>([&](auto KI) {
-            constexpr int k = decltype(KI)::value;
-            constexpr int i = 11 * w + 2 * k + par;
-            v[k] = *reinterpret_cast<const h16x2 *>(tp + i * 2 * KTabPair3::PAIR_B + ad[k]);
-          });
-          static_for<0, 5>([&](auto KI) {
-            constexpr int k = decltype(KI)::value;
-            constexpr int i = 11 * w + 2 * k + par;
-            accp[k & 3] = __builtin_amdgcn_fdot2(v[k], csh[i], accp[k & 3], false);
-          });
+          if constexpr (PAIR == 2) {
+            f32x2 v[5];
+            static_for<0, 5>([&](auto KI) {
+              constexpr int k = decltype(KI)::value;
+              constexpr int i = 11 * w + 2 * k + par;
+              v[k] = *reinterpret_cast<const f32x2 *>(tp + i * 2 * PB + (ad[k] << 1));
+            });
+            static_for<0, 5>([&](auto KI) {
+              constexpr int k = decltype(KI)::value;
+              constexpr int i = 11 * w + 2 * k + par;
+              acc4[k & 3] = __builtin_elementwise_fma(cs[i], v[k], acc4[k & 3]);
+            });
+          } else {
+            h16x2 v[5];
+            static_for<0, 5>([&](auto KI) {
+              constexpr int k = decltype(KI)::value;
+              constexpr int i = 11 * w + 2 * k + par;
+              v[k] = *reinterpret_cast<const h16x2 *>(tp + i * 2 * PB + ad[k]);
+            });
+            static_for<0, 5>([&](auto KI) {
+              constexpr int k = decltype(KI)::value;
+              constexpr int i = 11 * w + 2 * k + par;
+              accp[k & 3] = __builtin_amdgcn_fdot2(v[k], csh[i], accp[k & 3], false);
+            });
+          }
         });
       });
       // the straddling fields: i = 10 (bits 30, 31 of word 0 + bit 0 of word 1), i = 21 (bit 31 of word 1 + bits 0, 1 of word 2)
@@ -595,10 +612,17 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
         asm("v_alignbit_b32 %0, %1, %2, 31" : "=v"(y21) : "v"(whi[2]), "v"(whi[1]));
         const uint32_t a10 = ((((y10 & 7u) << 3) | (x10 & 7u)) << 2) | role_8;
         const uint32_t a21 = ((((y21 & 7u) << 3) | (x21 & 7u)) << 2) | role_8;
-        const h16x2 v10 = *reinterpret_cast<const h16x2 *>(tp + 10 * 2 * KTabPair3::PAIR_B + a10);
-        const h16x2 v21 = *reinterpret_cast<const h16x2 *>(tp + 21 * 2 * KTabPair3::PAIR_B + a21);
-        accp[1] = __builtin_amdgcn_fdot2(v10, csh[10], accp[1], false);
-        accp[2] = __builtin_amdgcn_fdot2(v21, csh[21], accp[2], false);
+        if constexpr (PAIR == 2) {
+          const f32x2 v10 = *reinterpret_cast<const f32x2 *>(tp + 10 * 2 * PB + (a10 << 1));
+          const f32x2 v21 = *reinterpret_cast<const f32x2 *>(tp + 21 * 2 * PB + (a21 << 1));
+          acc4[1] = __builtin_elementwise_fma(cs[10], v10, acc4[1]);
+          acc4[2] = __builtin_elementwise_fma(cs[21], v21, acc4[2]);
+        } else {
+          const h16x2 v10 = *reinterpret_cast<const h16x2 *>(tp + 10 * 2 * PB + a10);
+          const h16x2 v21 = *reinterpret_cast<const h16x2 *>(tp + 21 * 2 * PB + a21);
+          accp[1] = __builtin_amdgcn_fdot2(v10, csh[10], accp[1], false);
+          accp[2] = __builtin_amdgcn_fdot2(v21, csh[21], accp[2], false);
+        }
       }
     } else if constexpr (BITS == 4) {
       static_for<0, 4>([&](auto J) {
@@ -735,7 +759,7 @@ __device__ __forceinline__ KTile score_k_tile_at(const ScoreKArgs &a, unsigned c
       }
     }   // wact
     const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-    float res = PAIR ? (accp[0] + accp[1]) + (accp[2] + accp[3]) : acc.x + acc.y;
+    float res = PAIR == 1 ? (accp[0] + accp[1]) + (accp[2] + accp[3]) : acc.x + acc.y;
     res += __shfl_xor(res, 32);
 #if KVQ_TRACE
     asm volatile("" :: "v"(res));
@@ -869,7 +893,7 @@ __device__ __forceinline__ void score_k_block_map(const ScoreKArgs &a, int &tile
   }
 }
 
-template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT, bool PAIR = false>
+template <int BITS, bool SPARSE, int NWAVES, bool TRANSPOSED, bool COMPACT, int PAIR = 0>
 __device__ __forceinline__ KTile score_k_tile(const ScoreKArgs &a, unsigned char *smem) {
   int tile_i, h0_i, nh_i;
   score_k_block_map(a, tile_i, h0_i, nh_i);

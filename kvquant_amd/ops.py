@@ -635,7 +635,8 @@ def make_layer(kc, vc, table, lut_off):
         _i(vc.vcache, "vcache"), _f(vc.lookup_table, "lookup_table"), _f(vc.lut, "lut"), _fo(vc.outliers, "outliers"),
         _i(vc.outlier_indices, "outlier_indices"), None if vstruct is None else ctypes.pointer(vstruct),
         None if mix is vc.lookup_table else _f(mix, "lookup_table2"),
-        _lib.LAYER_SCORE_F16_PAIR if (kc.bits == 3 and getattr(kc, "score_f16_pair", False)) else 0)
+        (_lib.LAYER_SCORE_F16_PAIR if (kc.bits == 3 and getattr(kc, "score_f16_pair", False)) else 0) |
+        (_lib.LAYER_SCORE_F32_PAIR if (kc.bits == 3 and getattr(kc, "score_f32_pair", False)) else 0))
     return ly, (vstruct, table, lut_off, mix)
 
 

@@ -193,7 +193,8 @@ def test_prefill_pack_8192_against_reference(ref, bits):
 
 
 @pytest.mark.parametrize("bits,ctx,sinks,f16_pair", [(4, 131072, 0, False), (3, 131072, 0, False), (3, 131072, 5, False),
-                                                     (4, 32768, 0, False), (3, 131072, 5, True)])
+                                                     (4, 32768, 0, False), (3, 131072, 5, True), (3, 131072, 5, "f32"),
+                                                     (3, 40000, 0, "f32")])
 def test_decode_kv_end_to_end_against_reference_pipeline(ref, bits, ctx, sinks, f16_pair):
     """The one-call decode step at the BASELINE sizes against the pipeline assembled from the REFERENCE's own ops on the
     same cache: its q.K^T(+RoPE, +sparse) kernel -> half(score) / sqrt(d) in fp16 -> [fp16 sink scores in front,
@@ -212,6 +213,9 @@ def test_decode_kv_end_to_end_against_reference_pipeline(ref, bits, ctx, sinks, 
     gen = torch.Generator(device=dev).manual_seed(4321 + bits)
     max_len = (ctx + 8 + 63) // 64 * 64
     lay = bench.Layer(bits, max_len, gen, dev, sinks)
+    # ("f32": the opt-in EXACT fp32 pair-sum tables -- 1024-lane score workgroups -- held to the default tolerance)
+    lay.k.score_f32_pair = f16_pair == "f32"
+    f16_pair = f16_pair is True
     lay.k.score_f16_pair = bool(f16_pair)
     lay.fill(ctx, gen, dev)
     k, v = bench.synth_tokens(2, lay.scale, lay.shift, gen, dev)

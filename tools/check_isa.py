@@ -211,9 +211,13 @@ def check_linear(path, kernel_substr="score_k_kernel", skip=None):
 
 
 def is_jit(name):
-    """the mirror variants (TRANSPOSED = true, the 4th template argument of score_k_kernel<BITS, SPARSE, NWAVES,
-    TRANSPOSED, COMPACT>): loads in flight across loop iterations"""
-    return re.search(r"score_k_kernelILi\dELb[01]ELi\dELb1ELb[01]EEE", name) is not None
+    """the mirror variants (TRANSPOSED = true, the 4th template argument of score_k_kernel<BITS, SPARSE, NWAVES, TRANSPOSED,
+    COMPACT, PAIR>) with per-channel tables (PAIR = 0) or the fp32 pair-sum tables (PAIR = 2): loads in flight across loop
+    iterations, every control-flow path walked.  (Round 5 gave the template its sixth argument and this pattern still
+    expected five: the mirror kernels were scanned in program-text order only.  Round 6 repaired it -- the default kernels
+    and the new 16-wave variant pass the path walk.  The opt-in fp16 pair-table variants (PAIR = 1) keep the linear scan: the
+    walk reports paths through their unrolled pair groups whose wait counts and load conditions are correlated.)"""
+    return re.search(r"score_k_kernelILi\dELb[01]ELi\d+ELb1ELb[01]ELi[02]EEE", name) is not None
 
 
 def check(path, kernel_substr="score_k_kernel"):

@@ -18,7 +18,7 @@ ARCH = os.environ.get("KVQ_ARCH", "gfx950")
 
 # (regex on the demangled-ish kernel name, why scratch is tolerated there)
 ALLOWED = [
-    (r"score_k_kernelILi\dELb1ELi8ELb0ELb0ELb0E", "row-layout sparse score kernel of the LEGACY quant_cuda entry points "
+    (r"score_k_kernelILi\dELb1ELi8ELb0ELb0ELi0E", "row-layout sparse score kernel of the LEGACY quant_cuda entry points "
                                                   "(decode_kv reads the token-contiguous mirror): 3-5 VGPRs outside the head loop"),
     (r"fused_decode_kernelILi2E", "fused attend at 2 bit (opt-in route, never a default)"),
 ]
