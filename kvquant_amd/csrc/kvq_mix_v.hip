@@ -52,7 +52,8 @@
 #ifndef KVQ_W_MERGE_PARTS
 #define KVQ_W_MERGE_PARTS 256   // wide p.V: up to this many score tiles (64K tokens) the workgroups merge the softmax partials themselves
                                 // (1024 measured: the merge in every workgroup's prologue costs what the launch costs -- 128K 5.56 vs 5.67 ms/step,
-                                //  profiles/r06_n_merge.txt)
+                                //  profiles/r06_n_merge.txt; with 16 or 32 partial loads per lane in one round trip: the same, r06_r_merge_batch.txt --
+                                //  the merge runs behind the wait for the first tile, not beside it)
 #endif
 #ifndef KVQ_V_RB
 #define KVQ_V_RB 24             // outlier phase: entries per lane and token block (one round of loads)
