@@ -35,9 +35,6 @@
 #ifndef KVQ_W_BURST
 #define KVQ_W_BURST 0     // 1: the next tile's pieces in one burst behind the barrier instead of a piece per quad
 #endif
-#ifndef KVQ_W_MERGE_BATCH
-#define KVQ_W_MERGE_BATCH 8
-#endif
 #ifndef KVQ_W_NT
 #define KVQ_W_NT 0        // 1: the tile rows with the non-temporal load policy
 #endif
@@ -331,7 +328,7 @@ __global__ __launch_bounds__(1024) void mix_v_wide_kernel(WideArgs wa) {
         static_assert(CT == 32, "a head's scores of a chunk are converted by half a wave");
         const float2 *pr = reinterpret_cast<const float2 *>(a.parts) + (int64_t)hc * a.n_parts;
         float M = -INFINITY, Z = 0.f;
-        constexpr int MB = KVQ_W_MERGE_BATCH;      // partials per lane and round trip
+        constexpr int MB = 8;
         for (int i0 = tid & 31; i0 < a.n_parts; i0 += 32 * MB) {
           float2 ms[MB];
 #pragma unroll
