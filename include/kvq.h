@@ -67,6 +67,9 @@ extern "C" {
  *        through them) run the one-workgroup-per-CU kernel (kvq_mix_v_wide.hip) for q_len = 1 from 6144 cached tokens on --
  *        same arguments, same workspace size, the outlier sums are still exact (64-bit fixed point) and order independent;
  *        kvq_head_shard_step validates every argument before its first launch.
+ *   402  round 6: new entries kvq_score_k_mirror, kvq_outlier_mirror_rows (the mirror variant of q.K^T for callers that
+ *        keep the reference's outlier rows); new flag values KVQ_SCORE_F32_PAIR_TABLES / KVQ_LAYER_SCORE_F32_PAIR;
+ *        kvq_score_k_workspace_bytes is 16 KB per head larger at 3 bit.
  *        A binding checks `kvq_version() / 100 == KVQ_ABI_MAJOR`. */
 #define KVQ_ABI_MAJOR 4
 KVQ_API int kvq_version(void);
@@ -302,6 +305,20 @@ KVQ_API int kvq_score_k_softmax_parts(int bits, int64_t L, int sparse);
  * heads per workgroup and `slots` = workgroups the GPU holds at once (512 on MI355X for the 256-token kernel).  The
  * reference launches one block per (128 tokens, head) whatever the size (KCU:3437-3488); here the grid is planned with
  * a makespan model (kvq_score_k.hip, pick_groups).  0 = invalid arguments. */
+/* round 6 (ABI 402).  kvq_score_k (above) over the token-contiguous outlier MIRROR f32 / i32 [n_out][max_len] instead of
+ * the reference's rows [max_len][n_out]: the decode kernel's fast variant (a lane owns its token's entries; 82 - 87 us
+ * against 117 us through the rows at 128K nuq4) behind the legacy call's semantics -- tables built from q, `mul`
+ * accumulated (accumulate = 1, what quant_cuda's _opt2 functions do, KCPP:205-212) or overwritten.  q [H][128] f32, q_len = 1.
+ * kvq_outlier_mirror_rows fills columns [t0, t1) of a mirror from rows [t0, t1) of the reference layout (KCU:473-521 reads
+ * the rows; modeling_llama.py:742-751 writes them): a caller that keeps the rows as the source of truth transposes what
+ * it appended since its last call.  kvquant_amd.quant_cuda does exactly that behind the module swap. */
+KVQ_API int kvq_score_k_mirror(int bits, const float *q, const int32_t *mat, float *mul, const float *lut, int H,
+                               int hd, int64_t L, int64_t max_len, float rope_theta, int pos_offset,
+                               const float *outliers_t, const int32_t *outlier_idx_t, int n_out, int accumulate,
+                               void *workspace, size_t workspace_bytes, void *stream);
+KVQ_API int kvq_outlier_mirror_rows(const float *outliers, const int32_t *outlier_idx, float *outliers_t,
+                                    int32_t *outlier_idx_t, int n_out, int64_t max_len, int64_t t0, int64_t t1,
+                                    void *stream);
 KVQ_API int kvq_score_k_head_groups(int H, int64_t tiles, int q_len, int max_heads_per_group, int slots);
 KVQ_API int kvq_score_k_prepared_softmax(int bits, const int32_t *mat, float *mul,
                          const float *lut, int H, int hd, int64_t L, int64_t max_len,

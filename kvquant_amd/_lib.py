@@ -59,6 +59,8 @@ SIGNATURES = {
     "kvq_pack_v_sparse_parallel": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _vp]),
     "kvq_score_k_workspace_bytes": (_sz, [_i, _i, _i]),
     "kvq_score_k": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "kvq_score_k_mirror": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "kvq_outlier_mirror_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _vp]),
     "kvq_mix_v_workspace_bytes": (_sz, [_i, _i, _i, _i, _i64]),
     "kvq_mix_v": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "kvq_append_k_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _vp]),

@@ -30,7 +30,7 @@ int &last_hip_error_ref() {
 
 extern "C" {
 
-int kvq_version(void) { return 401; }    // history: include/kvq.h
+int kvq_version(void) { return 402; }    // history: include/kvq.h
 
 const char *kvq_strerror(int code) {
   switch (code) {

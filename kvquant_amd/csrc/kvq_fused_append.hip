@@ -13,9 +13,13 @@
 #include "kvq_common.h"
 #include "kvq_host.h"
 #include "kvq_ktab.h"
+#include "kvq_select.h"
 
 #include <cstdlib>
 
+#ifndef KVQ_FAST_SELECT
+#define KVQ_FAST_SELECT 1    // outlier selection by pruning + bitwise search (kvq_select.h); 0: the four-pass radix select (A/B runs)
+#endif
 #ifndef KVQ_PACK_TILED
 #define KVQ_PACK_TILED 1     // prefill pack: four tokens per workgroup, the prompt read once (kvq_pack_tiled.h); 0: the
 #endif                       // per-token workgroups (A/B runs)
@@ -44,13 +48,17 @@ struct SelShared {
   // [pass parity][side][copy][digit]: the next pass's histogram is zeroed during this pass's scan; lanes spread over
   // HC copies of a histogram (same-address LDS atomics serialise: the first pass puts 4096 elements into ~10 bins)
   static constexpr int HC = NT >= 1024 ? 4 : 1;
-  uint32_t hist[2][2][HC][256];
+  uint32_t hist[2][2][HC][256];    // (the candidate lists of the pruning select alias it: kvq_select.h, FselShared)
+  FselCtl fctl;
+  uint32_t fallback;
   uint32_t wsum[NT / 64 + 1];
   uint32_t prefix[2];
   uint32_t krem[2];
   uint32_t scan[NT / 64];
   unsigned codes[E * NT + E * NT / 32];   // channel c at c + c/32: the pack's lane-per-group reads are conflict free
 };
+
+static_assert(sizeof(FselShared) <= sizeof(uint32_t) * 2 * 2 * 256, "the candidate lists alias one histogram copy");
 
 // inclusive prefix sum over the 64 lanes of a wave with DPP row operations: six dependent VALU instructions instead of
 // six ds_bpermute round trips (the select is a chain of latencies: four passes x (atomics, barrier, scan, barrier))
@@ -290,20 +298,49 @@ __device__ __forceinline__ void fused_append_body(const AppendArgs &A) {
   const uint32_t ksel = IS_V ? (uint32_t)(thr_k + 1) : (uint32_t)thr_k;   // V: threshold is the (thr_k+1)-th
   asm volatile("" :: "v"(key[0]), "v"(end_lo[0]));
   KVQ_STAMP(A, 1);
-  radix_select_both<NT, E>(key, ok, ksel, sh, T, gt);
+  uint32_t eq_hi = 0, eq_lo = 0;          // #keys equal to each threshold
+  bool radix = !KVQ_FAST_SELECT;
+  if constexpr (KVQ_FAST_SELECT != 0) {
+    // pruning select (kvq_select.h): candidates of every wave -> one list per side (aliases the histograms), one wave per
+    // side resolves it; a token whose list overflows -- hundreds of keys tied at the bound -- takes the radix select below
+    FselShared &fs = reinterpret_cast<FselShared &>(sh.hist);
+    fsel_bounds<E>(key, ok, ksel, NT / 64, tid >> 6, sh.fctl);
+    if (tid < 2) sh.fctl.ncand[tid] = 0;
+    if (tid == 0) sh.fallback = 0;
+    KVQ_STAMP(A, 7);
+    __syncthreads();
+    KVQ_STAMP(A, 8);
+    fsel_collect<E>(key, ok, NT / 64, fs, sh.fctl);
+    KVQ_STAMP(A, 9);
+    __syncthreads();
+    KVQ_STAMP(A, 10);
+    if (tid < 128) {
+      if (!fsel_resolve(tid >> 6, ksel, fs, sh.fctl)) sh.fallback = 1;
+    }
+    KVQ_STAMP(A, 11);
+    __syncthreads();
+    KVQ_STAMP(A, 12);
+    radix = sh.fallback != 0;              // (block-uniform)
+    if (!radix) {
+      T[0] = sh.fctl.res[0][0]; gt[0] = sh.fctl.res[0][1]; eq_hi = sh.fctl.res[0][2];
+      T[1] = sh.fctl.res[1][0]; gt[1] = sh.fctl.res[1][1]; eq_lo = sh.fctl.res[1][2];
+    }
+  }
+  if (radix) {
+    radix_select_both<NT, E>(key, ok, ksel, sh, T, gt);
+    // (the last radix pass left the number of elements equal to each threshold in its histogram, pass 0: parity 0)
+    for (int q = 0; q < SelShared<NT, E>::HC; q++) {
+      eq_hi += sh.hist[0][0][q][T[0] & 0xffu];
+      eq_lo += sh.hist[0][1][q][T[1] & 0xffu];
+    }
+  }
   KVQ_STAMP(A, 2);
 
   // ---- membership: strictly beyond the threshold, plus the first ties in channel order ----------
   // K keeps k = thr_k per side; V keeps the top thr_k of the thr_k+1 selected (the last-ranked one,
   // i.e. the highest-index tie, is the clipping threshold itself: modeling_llama.py:1091-1096).
-  // (the last radix pass left the number of elements equal to each threshold in its histogram: when it is exactly
-  //  the number still wanted, or none is wanted -- no run of ties is cut, the usual case -- the ranks are not needed
-  //  and the block scan is skipped)
-  uint32_t eq_hi = 0, eq_lo = 0;                                        // (pass 0: parity 0)
-  for (int q = 0; q < SelShared<NT, E>::HC; q++) {
-    eq_hi += sh.hist[0][0][q][T[0] & 0xffu];
-    eq_lo += sh.hist[0][1][q][T[1] & 0xffu];
-  }
+  // (when the number of elements equal to a threshold is exactly the number still wanted, or none is wanted -- no run of
+  //  ties is cut, the usual case -- the ranks are not needed and the block scan is skipped)
   const uint32_t w_hi = (uint32_t)thr_k - gt[0], w_lo = (uint32_t)thr_k - gt[1];
   const bool cut = !((w_hi == 0 || eq_hi == w_hi) && (w_lo == 0 || eq_lo == w_lo));   // (block-uniform)
   uint32_t rank_hi = 0, rank_lo = 0;

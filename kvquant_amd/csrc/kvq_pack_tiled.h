@@ -45,7 +45,8 @@ constexpr int kTHC = KVQ_PACK_THC;   // copies of a selection histogram, lanes s
                                      // changed nothing measurable at four tokens per workgroup; one copy is what lets three
                                      // workgroups share a CU at two tokens
 struct TiledSel {
-  uint32_t hist[2][2][kTHC][256];     // [pass parity][side][copy][digit]
+  uint32_t hist[2][2][kTHC][256];     // [pass parity][side][copy][digit]; the pruning select's candidate lists alias it
+  FselCtl fctl;
   uint32_t prefix[2], krem[2];
   uint32_t scan[kTG / 64];
   float vrow[16], vrow2[16];
@@ -56,7 +57,9 @@ struct TiledShared {
   unsigned char cb[kTT][kTC + 16];        // codes (+16: the tokens of a 32-channel group in different banks for the pack's reads)
   TiledSel sel[kTT];
   int any_cut;
+  uint32_t fallback;                      // a token group's candidate list overflowed: every group takes the radix select
 };
+static_assert(sizeof(FselShared) <= sizeof(uint32_t) * 2 * 2 * kTHC * 256, "the candidate lists alias the histograms");
 
 // exclusive scan over the kTG lanes of a token group (whole-workgroup barriers: every group calls it together)
 __device__ __forceinline__ uint32_t group_excl_scan(uint32_t v, uint32_t *ws, int tg, uint32_t &total) {
@@ -199,7 +202,11 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
       for (int t = 0; t < kTT; t++) sh.ss[t][cp] = xv[t];
     }
   }
-  if (tid == 0) sh.any_cut = 0;
+  if (tid == 0) {
+    sh.any_cut = 0;
+    sh.fallback = 0;
+  }
+  if (tid < 2 * kTT) sh.sel[tid >> 1].fctl.ncand[tid & 1] = 0;
   __syncthreads();
 
   // ---- phase 2: group = token ------------------------------------------------------------------------------------
@@ -224,14 +231,33 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
   }
   uint32_t T[2], gtc[2];
   const uint32_t ksel = IS_V ? (uint32_t)(thr_k + 1) : (uint32_t)thr_k;
-  group_select_both(key, ok, ksel, ts, tg, T, gtc);
-
-  // membership: strictly beyond the threshold, plus the first ties in channel order (fused_append_body)
   uint32_t eq_hi = 0, eq_lo = 0;
+  bool radix = !KVQ_FAST_SELECT;
+  if constexpr (KVQ_FAST_SELECT != 0) {
+    // pruning select (kvq_select.h; round 6): three barriers instead of the radix chain's nine, no histogram atomics
+    FselShared &fs = reinterpret_cast<FselShared &>(ts.hist);
+    fsel_bounds<kTE>(key, ok, ksel, kTG / 64, tg >> 6, ts.fctl);
+    __syncthreads();
+    fsel_collect<kTE>(key, ok, kTG / 64, fs, ts.fctl);
+    __syncthreads();
+    if (tg < 128) {
+      if (!fsel_resolve(tg >> 6, ksel, fs, ts.fctl)) sh.fallback = 1;
+    }
+    __syncthreads();
+    radix = sh.fallback != 0;            // (workgroup-uniform: the radix select has barriers inside)
+    if (!radix) {
+      T[0] = ts.fctl.res[0][0]; gtc[0] = ts.fctl.res[0][1]; eq_hi = ts.fctl.res[0][2];
+      T[1] = ts.fctl.res[1][0]; gtc[1] = ts.fctl.res[1][1]; eq_lo = ts.fctl.res[1][2];
+    }
+  }
+  if (radix) {
+    group_select_both(key, ok, ksel, ts, tg, T, gtc);
+    // membership: strictly beyond the threshold, plus the first ties in channel order (fused_append_body)
 #pragma unroll
-  for (int q = 0; q < kTHC; q++) {
-    eq_hi += ts.hist[0][0][q][T[0] & 0xffu];
-    eq_lo += ts.hist[0][1][q][T[1] & 0xffu];
+    for (int q = 0; q < kTHC; q++) {
+      eq_hi += ts.hist[0][0][q][T[0] & 0xffu];
+      eq_lo += ts.hist[0][1][q][T[1] & 0xffu];
+    }
   }
   const uint32_t want_hi = (uint32_t)thr_k - gtc[0], want_lo = (uint32_t)thr_k - gtc[1];
   const bool cut = !((want_hi == 0 || eq_hi == want_hi) && (want_lo == 0 || eq_lo == want_lo));   // (group-uniform)

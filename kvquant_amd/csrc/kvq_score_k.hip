@@ -246,6 +246,9 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
     return a.L >= 16384 ? launch_score<BITS, true, 8, true>(a, q_len, theta, st)
                         : launch_score<BITS, true, 4, true>(a, q_len, theta, st);
   }
+  // (row-layout outliers -- the legacy entry points: 4-wave tiles measured 53.0 -> 46.4 us at 32K and 105 -> 123 at 128K,
+  //  profiles/r06_t_rows_ab.txt; not adopted: the fused-softmax form of the same call counts 256-token tiles from 16K on, and the
+  //  two forms are held bit-identical -- tests/test_fused_gpu.py)
   if (a.L >= 16384) {
     return sparse ? launch_score<BITS, true, 8>(a, q_len, theta, st) : launch_score<BITS, false, 8>(a, q_len, theta, st);
   }
@@ -256,6 +259,37 @@ static size_t ws_bytes(int bits, int q_len, int H) {
   return bits == 4 ? ktab_total_bytes<4>(q_len, H) : (bits == 3 ? ktab_total_bytes<3>(q_len, H) : ktab_total_bytes<2>(q_len, H));
 }
 
+}  // namespace kvq
+
+
+namespace kvq {
+// rows [t0, t1) of the reference's outlier rows [max_len][n_out] -> columns of the token-contiguous mirror [n_out][max_len]
+// (64 tokens per block through an LDS tile: both sides coalesced)
+__global__ __launch_bounds__(256) void mirror_rows_kernel(const float *__restrict__ rows_v, const int32_t *__restrict__ rows_i,
+                                                          float *__restrict__ out_t, int32_t *__restrict__ idx_t, int n_out,
+                                                          int64_t max_len, int64_t t0, int64_t t1) {
+  __shared__ float tv[64][65];
+  __shared__ int32_t ti[64][65];
+  const int64_t b0 = t0 + (int64_t)blockIdx.x * 64;
+  const int nt = (t1 - b0 < 64) ? (int)(t1 - b0) : 64;
+  for (int s0 = 0; s0 < n_out; s0 += 64) {
+    const int ns = (n_out - s0 < 64) ? n_out - s0 : 64;
+    for (int e = threadIdx.x; e < nt * ns; e += 256) {
+      const int t = e / ns, sl = e % ns;
+      tv[t][sl] = rows_v[(b0 + t) * n_out + s0 + sl];
+      ti[t][sl] = rows_i[(b0 + t) * n_out + s0 + sl];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ns * 64; e += 256) {
+      const int sl = e / 64, t = e % 64;
+      if (t < nt) {
+        out_t[(int64_t)(s0 + sl) * max_len + b0 + t] = tv[t][sl];
+        idx_t[(int64_t)(s0 + sl) * max_len + b0 + t] = ti[t][sl];
+      }
+    }
+    __syncthreads();
+  }
+}
 }  // namespace kvq
 
 using namespace kvq;
@@ -326,6 +360,32 @@ int kvq_score_k(int bits, const float *q, const int32_t *mat, float *mul, const 
                 void *stream) {
   return score_entry(bits, q, 0, 0, mat, mul, lut, q_len, H, hd, L, max_len, rope_theta, pos_offset, outliers,
                      outlier_idx, n_out, accumulate, workspace, workspace_bytes, stream);
+}
+
+
+/* kvq_score_k over the token-contiguous outlier MIRROR [n_out][max_len] (kvq.h 2: what kvquant_amd.cache.QuantK keeps next to
+ * the reference's rows) instead of the rows: the decode kernel's fast variant behind the legacy call's semantics (tables built
+ * from q here, `mul` accumulated or overwritten).  q_len = 1. */
+int kvq_score_k_mirror(int bits, const float *q, const int32_t *mat, float *mul, const float *lut, int H, int hd, int64_t L,
+                       int64_t max_len, float rope_theta, int pos_offset, const float *outliers_t,
+                       const int32_t *outlier_idx_t, int n_out, int accumulate, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+  if (!outliers_t || !outlier_idx_t) return KVQ_EINVAL;
+  return score_entry(bits, q, 0, 0, mat, mul, lut, 1, H, hd, L, max_len, rope_theta, pos_offset, nullptr, nullptr, n_out,
+                     accumulate, workspace, workspace_bytes, stream, nullptr, 0.f, 0, outliers_t, outlier_idx_t);
+}
+
+/* Rows [t0, t1) of outlier rows in the reference's layout (f32 / i32 [max_len][n_out]) -> the same columns of the
+ * token-contiguous mirror (f32 / i32 [n_out][max_len]).  For callers that keep the reference's rows as the source of truth and
+ * want the decode kernel's mirror variant (kvquant_amd.quant_cuda does this behind the module swap). */
+int kvq_outlier_mirror_rows(const float *outliers, const int32_t *outlier_idx, float *outliers_t, int32_t *outlier_idx_t,
+                            int n_out, int64_t max_len, int64_t t0, int64_t t1, void *stream) {
+  if (!outliers || !outlier_idx || !outliers_t || !outlier_idx_t || n_out <= 0 || t0 < 0 || t1 > max_len || t0 > t1)
+    return KVQ_EINVAL;
+  if (t0 == t1) return KVQ_OK;
+  const unsigned blocks = (unsigned)((t1 - t0 + 63) / 64);
+  mirror_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(outliers, outlier_idx, outliers_t, outlier_idx_t, n_out, max_len, t0, t1);
+  return check_launch();
 }
 
 int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const float *lut, int H, int hd, int64_t L,

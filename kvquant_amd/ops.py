@@ -182,6 +182,40 @@ def score_k(bits, q, mat, mul, lut, L, theta, pos_offset, outliers=None, outlier
             1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "kvq_score_k")
 
 
+def outlier_mirror_rows(outliers, outlier_indices, outliers_t, outlier_indices_t, t0, t1):
+    """rows [t0, t1) of the reference's outlier rows [max_len, n_out] -> columns [t0, t1) of the token-contiguous
+    mirror [n_out, max_len] (include/kvq.h: kvq_outlier_mirror_rows)."""
+    max_len, n_out = outliers.shape
+    if tuple(outlier_indices.shape) != (max_len, n_out) or tuple(outliers_t.shape) != (n_out, max_len) or \
+            tuple(outlier_indices_t.shape) != (n_out, max_len):
+        raise ValueError("outlier rows must be [max_len, n_out] and the mirror [n_out, max_len]")
+    with _Dev(outliers):
+        _lib.check(_L().kvq_outlier_mirror_rows(
+            _f(outliers, "outliers"), _i(outlier_indices, "outlier_indices"), _f(outliers_t, "outliers_t"),
+            _i(outlier_indices_t, "outlier_indices_t"), n_out, max_len, int(t0), int(t1), _stream()),
+            "kvq_outlier_mirror_rows")
+
+
+def score_k_mirror(bits, q, mat, mul, lut, L, theta, pos_offset, outliers_t, outlier_indices_t, accumulate=True):
+    """score_k (q_len = 1) over the token-contiguous outlier mirror [n_out, max_len]: the decode kernel's variant behind
+    the legacy call's semantics (include/kvq.h: kvq_score_k_mirror)."""
+    H, hd, max_len = _cache_dims(mat, bits)
+    if q.dim() != 3 or mul.dim() != 3 or q.shape[0] != 1 or mul.shape[0] != 1:
+        raise ValueError("vec must be [1, H, head_dim] and mul [1, H, kcachelen]")
+    if mul.shape[2] != L:
+        raise ValueError("mul.shape[2] must equal kcachelen")
+    n_out = outliers_t.shape[0]
+    if tuple(outliers_t.shape) != (n_out, max_len) or tuple(outlier_indices_t.shape) != (n_out, max_len):
+        raise ValueError("the outlier mirror must be [n_out, max_len]")
+    with _Dev(q):
+        nbytes = _L().kvq_score_k_workspace_bytes(bits, 1, H)
+        ws = _workspace(q.device, nbytes, slot="score")
+        _lib.check(_L().kvq_score_k_mirror(
+            bits, _f(q, "vec"), _i(mat, "mat"), _f(mul, "mul"), _f(lut, "lookup_table"), H, hd, int(L), max_len,
+            float(theta), int(pos_offset), _f(outliers_t, "outliers_t"), _i(outlier_indices_t, "outlier_indices_t"),
+            n_out, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "kvq_score_k_mirror")
+
+
 def mix_v(bits, p, mat, mul, lut_rows, L, outliers=None, outlier_indices=None, accumulate=True):
     """p [q_len,H,L] f32, mul [q_len,H,128] f32 (in place)."""
     H, hd, max_len = _cache_dims(mat, bits)

@@ -7,9 +7,73 @@ Differences from the reference, all on the safe side:
   * kernels run on torch's CURRENT stream (the reference uses the null stream);
   * argument dtype / device / contiguity are checked and raise ValueError
     (the reference checks nothing and faults);
-  * no atomics: results are deterministic run to run.
+  * no atomics: results are deterministic run to run;
+  * the sparse q.K^T entry points (`..._rope_mha_batched_fused_opt2`, q_len = 1) keep a token-contiguous SHADOW MIRROR
+    of the caller's outlier rows and run the decode kernel's mirror variant on it (kvq_score_k_mirror: 82 - 87 us at
+    128K nuq4 against 117 us through the rows).  The caller's rows stay the source of truth: the rows appended since the
+    last call are transposed first (kvq_outlier_mirror_rows, one small launch), and ANY sign that older rows may have
+    changed -- another tensor object, another stream, a cache length that did not grow by exactly the number of in-place
+    writes torch counted on both arrays (`Tensor._version`; the reference's glue does one `outliers[klen] = ...` per
+    array and append, ML:748-749) -- re-transposes all of them (`shadow_invalidate` forces it).  `KVQ_QC_MIRROR=0` switches the shadow off (row
+    kernel, as in rounds 1 - 5); `KVQ_QC_MIRROR_FROM` = shortest cache that uses it.
 """
+import os
+import weakref
+
+import torch
+
 from . import ops
+
+QC_MIRROR = os.environ.get("KVQ_QC_MIRROR", "1") != "0"
+QC_MIRROR_FROM = int(os.environ.get("KVQ_QC_MIRROR_FROM", "16384"))
+_shadow = {}          # id(outliers tensor) -> _Shadow
+shadow_stats = {"full": 0, "incremental": 0}     # what the calls so far did (tests, tools/ref_bench.py)
+
+
+def shadow_invalidate(outliers=None):
+    """forget the shadow mirror of `outliers` (all of them: None).  For callers whose own kernels rewrite rows of a cache
+    that is then scored at a length one larger -- torch's version counters do not see such writes."""
+    if outliers is None:
+        _shadow.clear()
+    else:
+        _shadow.pop(id(outliers), None)
+
+
+class _Shadow:
+    __slots__ = ("ref_o", "ref_i", "ptr_o", "ptr_i", "shape", "length", "ver_o", "ver_i", "stream", "out_t", "idx_t")
+
+
+def _shadow_mirror(outliers, outlier_indices, L):
+    """the shadow mirror of (outliers, outlier_indices) with columns [0, L) current; None = use the row kernel"""
+    max_len, n_out = outliers.shape
+    if n_out * max_len * 4 >= 1 << 32:
+        return None
+    key = id(outliers)
+    stream = torch.cuda.current_stream(outliers.device).cuda_stream
+    s = _shadow.get(key)
+    fresh = (s is None or s.ref_o() is not outliers or s.ref_i() is not outlier_indices or
+             s.ptr_o != outliers.data_ptr() or s.ptr_i != outlier_indices.data_ptr() or
+             s.shape != (max_len, n_out) or s.stream != stream)
+    if fresh:
+        s = _Shadow()
+        s.ref_o = weakref.ref(outliers, lambda _r, k=key: _shadow.pop(k, None))
+        s.ref_i = weakref.ref(outlier_indices)
+        s.ptr_o, s.ptr_i, s.shape, s.stream = outliers.data_ptr(), outlier_indices.data_ptr(), (max_len, n_out), stream
+        s.out_t = torch.empty((n_out, max_len), dtype=torch.float32, device=outliers.device)
+        s.idx_t = torch.empty((n_out, max_len), dtype=torch.int32, device=outliers.device)
+        s.length = 0
+        _shadow[key] = s
+        t0 = 0
+    else:
+        grown = L - s.length
+        d_o, d_i = outliers._version - s.ver_o, outlier_indices._version - s.ver_i
+        # (a call at an unchanged length is re-transposed too: a writer that bypasses torch -- a custom kernel -- leaves no
+        #  trace in the counters, and a second score over the same cache is not what the reference's decode loop does)
+        t0 = s.length if (grown >= 1 and d_o == grown and d_i == grown) else 0
+    ops.outlier_mirror_rows(outliers, outlier_indices, s.out_t, s.idx_t, t0, L)
+    shadow_stats["full" if t0 == 0 else "incremental"] += 1
+    s.length, s.ver_o, s.ver_i = L, outliers._version, outlier_indices._version
+    return s
 
 
 def _make(bits):
@@ -45,6 +109,14 @@ def _make(bits):
         ops.score_k(bits, vec, mat, mul, lookup_table, kcachelen, theta, pos_offset)
 
     def k_opt2(vec, mat, mul, lookup_table, kcachelen, outliers, outlier_indices, theta, pos_offset):
+        if QC_MIRROR and vec.shape[0] == 1 and kcachelen >= QC_MIRROR_FROM and outliers.dim() == 2 and \
+                outliers.dtype == torch.float32 and outlier_indices.dtype == torch.int32 and \
+                outliers.is_contiguous() and outlier_indices.is_contiguous() and \
+                outliers.shape == outlier_indices.shape and kcachelen <= outliers.shape[0]:
+            s = _shadow_mirror(outliers, outlier_indices, int(kcachelen))
+            if s is not None:
+                ops.score_k_mirror(bits, vec, mat, mul, lookup_table, kcachelen, theta, pos_offset, s.out_t, s.idx_t)
+                return
         ops.score_k(bits, vec, mat, mul, lookup_table, kcachelen, theta, pos_offset, outliers, outlier_indices)
 
     def v_opt(vec, mat, mul, lookup_table, vcachelen):

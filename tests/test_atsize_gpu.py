@@ -73,6 +73,13 @@ def test_matvecs_at_size_against_reference(ref, bits, L, max_len, pos_offset):
     s_rows = torch.zeros(1, H, L, device=dev)
     ops.score_k(bits, d["q"], d["kmat"], s_rows, d["klut"], L, 10000.0, pos_offset, d["kvals"], d["kidx"], accumulate=False)
     e_rows = util.rel_err(s_rows[0], s_ref[0])
+    # the module swap's call: kvquant_amd.quant_cuda's shadow mirror + the decode kernel's mirror variant
+    from kvquant_amd import quant_cuda as qc
+    s_qc = torch.zeros(1, H, L, device=dev)
+    getattr(qc, kname)(d["q"], d["kmat"], s_qc, d["klut"], L, d["kvals"], d["kidx"], 10000.0, pos_offset)
+    e_qc = util.rel_err(s_qc[0], s_ref[0])
+    qc.shadow_invalidate()
+    assert e_qc < TOL, e_qc
     # the decode path's variant: tables from a prep call, token-contiguous outlier mirror, fused softmax partials
     ws = ops._workspace(dev, ops._L().kvq_score_k_workspace_bytes(bits, 1, H), slot="score")
     n_parts = ops._L().kvq_score_k_softmax_parts(bits, L, 1)

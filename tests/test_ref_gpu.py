@@ -242,6 +242,77 @@ def test_score_k(ref, qc, orc, bits, L, q_len, pos_offset, sparse):
 
 
 @pytest.mark.parametrize("bits", [4, 3, 2])
+def test_score_k_opt2_shadow_mirror_decode_pattern(ref, qc, bits):
+    """`..._rope_mha_batched_fused_opt2` through kvquant_amd.quant_cuda in the reference glue's decode pattern (ML:748-749:
+    one in-place row write per array and append, then the score call at a length one larger): the shadow mirror is
+    transposed in full on the first call, by one row on an append, in full again whenever older rows may have changed
+    (a rewritten row, a shorter cache, an unchanged length) -- and every result equals the reference's own kernel."""
+    name = "vecquant%dmatmul_nuq_perchannel_transposed_rope_mha_batched_fused_opt2" % bits
+    dev = torch.device("cuda:0")
+    L0, max_len = 17000, 20032
+    assert L0 >= qc.QC_MIRROR_FROM and qc.QC_MIRROR
+    lut = util.k_tables(bits, seed=bits)[0].to(dev)
+    mat = _random_cache(bits, max_len - 3, max_len, 99).to(dev)
+    vals, idx = [x.to(dev) for x in _outliers(max_len - 3, max_len, 5)]
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(1, H, HD, generator=g).half().float().to(dev)
+
+    def both(L):
+        r, h = torch.zeros(1, H, L, device=dev), torch.zeros(1, H, L, device=dev)
+        getattr(ref, name)(q, mat, r, lut, L, vals, idx, 10000.0, 7)
+        before = dict(qc.shadow_stats)
+        getattr(qc, name)(q, mat, h, lut, L, vals, idx, 10000.0, 7)
+        e = util.rel_err(h.cpu(), r.cpu())
+        assert e < TOL, (L, e)
+        return {k: qc.shadow_stats[k] - before[k] for k in before}, e
+
+    def glue_append(L):    # what ML:748-749 does for token L
+        gg = torch.Generator().manual_seed(1000 + L)
+        vals[L] = (torch.randn(42, generator=gg) * 3).to(dev)
+        idx[L] = torch.sort(torch.randperm(C, generator=gg)[:42]).values.to(torch.int32).to(dev)
+
+    qc.shadow_invalidate()
+    assert both(L0)[0] == {"full": 1, "incremental": 0}
+    errs = []
+    for L in range(L0, L0 + 5):
+        glue_append(L)
+        d, e = both(L + 1)
+        errs.append(e)
+        assert d == {"full": 0, "incremental": 1}, d
+    L = L0 + 5
+    # an older row rewritten next to the append: the counters moved by two, everything is transposed again
+    vals[17] = vals[17] * -2.0
+    glue_append(L)
+    assert both(L + 1)[0] == {"full": 1, "incremental": 0}
+    # the same length again, a shorter cache ("reset"), a jump of many rows written by ONE in-place operation (prefill)
+    assert both(L + 1)[0]["full"] == 1
+    assert both(16500)[0]["full"] == 1
+    vals[16500:16600] = vals[16500:16600] + 1.0
+    idx[16500:16600] = idx[16500:16600].clone()
+    assert both(16600)[0]["full"] == 1
+    # a writer torch's counters do not see (another handle on the same memory) + an ordinary append: the documented
+    # contract is shadow_invalidate()
+    alias = torch.from_dlpack(torch.utils.dlpack.to_dlpack(vals))
+    alias[33] = alias[33] * 0.5 + 1.0
+    glue_append(16600)
+    qc.shadow_invalidate(vals)
+    assert both(16601)[0] == {"full": 1, "incremental": 0}
+    # q_len = 2 and the switch: the row kernel
+    q2 = torch.cat([q, q * 0.5])
+    r, h = torch.zeros(2, H, 16601, device=dev), torch.zeros(2, H, 16601, device=dev)
+    before = dict(qc.shadow_stats)
+    getattr(ref, name)(q2, mat, r, lut, 16601, vals, idx, 10000.0, 7)
+    getattr(qc, name)(q2, mat, h, lut, 16601, vals, idx, 10000.0, 7)
+    assert qc.shadow_stats == before and util.rel_err(h.cpu(), r.cpu()) < TOL
+    qc.QC_MIRROR = False
+    try:
+        assert both(16601)[0] == {"full": 0, "incremental": 0}
+    finally:
+        qc.QC_MIRROR = True
+    print("bits=%d: shadow-mirror decode steps |HIP - reference| max %.2e" % (bits, max(errs)))
+
+
+@pytest.mark.parametrize("bits", [4, 3, 2])
 @pytest.mark.parametrize("L,q_len,sparse", [(1, 1, True), (63, 1, True), (1000, 2, False), (5001, 1, True),
                                              (20000, 1, True)])
 def test_mix_v(ref, qc, orc, bits, L, q_len, sparse):

@@ -45,3 +45,10 @@ for r, nm in enumerate(("K selection workgroup", "V append workgroup")):
     for p in range(6):
         print("   %-26s %6.2f us" % (names[p], acc[r, p] / N))
     print("   total %.2f us" % (acc[r].sum() / N))
+# pruning select (kvq_select.h), last iteration: stamps 8 .. 12 = zero + barrier | collect | barrier | resolve | barrier
+t = trace.cpu().double().view(2, 16)
+for r, nm in enumerate(("K", "V")):
+    if t[r, 8] > 0:
+        print(nm, "select detail (us): bounds %.2f, barrier %.2f, collect %.2f, barrier %.2f, resolve %.2f, barrier %.2f, ->2 %.2f" % (
+            (t[r, 7] - t[r, 1]) / 100, (t[r, 8] - t[r, 7]) / 100, (t[r, 9] - t[r, 8]) / 100, (t[r, 10] - t[r, 9]) / 100, (t[r, 11] - t[r, 10]) / 100,
+            (t[r, 12] - t[r, 11]) / 100, (t[r, 2] - t[r, 12]) / 100))

@@ -10,7 +10,7 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
-from kvquant_amd import ops  # noqa: E402
+from kvquant_amd import ops, quant_cuda  # noqa: E402
 from oracle import build_ref  # noqa: E402
 
 H, HD, C = 32, 128, 4096
@@ -62,6 +62,28 @@ def main():
             it[0] += 1
             ops.score_k(bits, q, mats[it[0] % 3], mk, lut, L, 10000.0, 0, vals, idx, accumulate=False)
 
+        # the module swap's call in the reference glue's decode pattern: one in-place row write per array
+        # (ML:748-749), a fresh zeroed `mul` (ML:778), then the score call at a length one larger -- the shadow mirror
+        # of kvquant_amd.quant_cuda takes one row per step
+        Lq = [L - 40]
+        newv, newi = vals[L - 1].clone(), idx[L - 1].clone()
+
+        def qc_k():
+            it[0] += 1
+            vals[Lq[0]] = newv
+            idx[Lq[0]] = newi
+            Lq[0] += 1
+            m = torch.zeros(1, H, Lq[0], device=dev)
+            getattr(quant_cuda, kname)(q, mats[it[0] % 3], m, lut, Lq[0], vals, idx, 10000.0, 0)
+
+        def ref_qc_k():      # the same pattern through the reference's kernel
+            it[0] += 1
+            vals[Lq[0]] = newv
+            idx[Lq[0]] = newi
+            Lq[0] += 1
+            m = torch.zeros(1, H, Lq[0], device=dev)
+            getattr(ref, kname)(q, mats[it[0] % 3], m, lut, Lq[0], vals, idx, 10000.0, 0)
+
         def ref_v():
             it[0] += 1
             mv.zero_()
@@ -71,6 +93,29 @@ def main():
             it[0] += 1
             ops.mix_v(bits, p, mats[it[0] % 3], mv, rows, L, vals, idx, accumulate=False)
         iters = 5 if L > 200000 else 10
+        if L > 64:
+            quant_cuda.shadow_invalidate()
+            before = dict(quant_cuda.shadow_stats)
+            tq = timeit(qc_k, iters)
+            did = {k: quant_cuda.shadow_stats[k] - before[k] for k in before}
+            Lq[0] = L - 40
+            tr = timeit(ref_qc_k, iters)
+            Lq[0] = L - 40
+            quant_cuda.QC_MIRROR = False
+            trow = timeit(qc_k, iters)
+            quant_cuda.QC_MIRROR = True
+            print(json.dumps({"op": "q.K^T + sparse through quant_cuda's _opt2, decode pattern (row write + zeroed mul + call)",
+                              "bits": bits, "L": L, "reference_kernel_us": round(tr, 1), "libkvq_us": round(tq, 1),
+                              "libkvq_row_kernel_us": round(trow, 1), "shadow_mirror_calls": did,
+                              "speedup": round(tr / tq, 2)}), flush=True)
+            vt, ixt = vals.t().contiguous(), idx.t().contiguous()
+
+            def our_km():
+                it[0] += 1
+                ops.score_k_mirror(bits, q, mats[it[0] % 3], mk, lut, L, 10000.0, 0, vt, ixt, accumulate=False)
+            print(json.dumps({"op": "q.K^T + sparse, kvq_score_k_mirror alone (tables + kernel)", "bits": bits, "L": L,
+                              "libkvq_us": round(timeit(our_km, iters), 1)}), flush=True)
+            del vt, ixt
         for op, rf, of, bpt in (("q.K^T + sparse (legacy row layout)", ref_k, our_k, C * bits // 8 + 336 + 128),
                                 ("p.V + sparse", ref_v, our_v, C * bits // 8 + 336 + 4 * n + 128)):
             tr, to = timeit(rf, iters), timeit(of, iters)
