@@ -206,6 +206,16 @@ static int launch_score(const ScoreKArgs &a0, int q_len, float rope_theta, hipSt
   return check_launch();
 }
 
+// cached tokens from which the sparse score kernels take 256-token tiles (8 waves); below: 128-token tiles (4 waves).
+// kvq_score_k_softmax_parts counts the same tiles.  KVQ_SCORE_T8_FROM: A/B runs.
+static int64_t big_tiles_from() {
+  static const int64_t v = [] {
+    const char *e = getenv("KVQ_SCORE_T8_FROM");
+    return e ? (int64_t)atoll(e) : (int64_t)16384;
+  }();
+  return v;
+}
+
 template <int BITS>
 static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int q_is_half, int tables_ready,
                           void *ws, int q_len, float theta, bool sparse, hipStream_t st) {
@@ -239,17 +249,17 @@ static int dispatch_score(ScoreKArgs a, const float *lut, const void *q_in, int 
   }
   // big tiles (8 waves) once there are enough of them, small tiles for short caches
   if (a.idx_t != nullptr && a.out_t == nullptr) {     // compact mirror
-    return a.L >= 16384 ? launch_score<BITS, true, 8, true, true>(a, q_len, theta, st)
+    return a.L >= big_tiles_from() ? launch_score<BITS, true, 8, true, true>(a, q_len, theta, st)
                         : launch_score<BITS, true, 4, true, true>(a, q_len, theta, st);
   }
   if (a.out_t != nullptr) {
-    return a.L >= 16384 ? launch_score<BITS, true, 8, true>(a, q_len, theta, st)
+    return a.L >= big_tiles_from() ? launch_score<BITS, true, 8, true>(a, q_len, theta, st)
                         : launch_score<BITS, true, 4, true>(a, q_len, theta, st);
   }
   // (row-layout outliers -- the legacy entry points: 4-wave tiles measured 53.0 -> 46.4 us at 32K and 105 -> 123 at 128K,
   //  profiles/r06_t_rows_ab.txt; not adopted: the fused-softmax form of the same call counts 256-token tiles from 16K on, and the
   //  two forms are held bit-identical -- tests/test_fused_gpu.py)
-  if (a.L >= 16384) {
+  if (a.L >= (sparse ? big_tiles_from() : (int64_t)16384)) {
     return sparse ? launch_score<BITS, true, 8>(a, q_len, theta, st) : launch_score<BITS, false, 8>(a, q_len, theta, st);
   }
   return sparse ? launch_score<BITS, true, 4>(a, q_len, theta, st) : launch_score<BITS, false, 4>(a, q_len, theta, st);
@@ -399,7 +409,7 @@ int kvq_score_k_prepared(int bits, const int32_t *mat, float *mul, const float *
 /* tiles of the sparse score kernel = (max, sum) partials per head it can write; 0: no fusion for this shape */
 int kvq_score_k_softmax_parts(int bits, int64_t L, int sparse) {
   if (bits < 2 || bits > 4 || L <= 0 || !sparse) return 0;
-  const int T = L >= 16384 ? 256 : 128;
+  const int T = L >= big_tiles_from() ? 256 : 128;
   return (int)((L + T - 1) / T);
 }
 
