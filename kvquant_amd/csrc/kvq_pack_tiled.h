@@ -145,7 +145,7 @@ __device__ __forceinline__ void group_select_both(const uint32_t (&key)[kTE], co
 }
 
 template <int BITS, bool IS_V>
-__global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t S) {
+__global__ __launch_bounds__(kTNT) __attribute__((amdgpu_waves_per_eu(6, 6))) void pack_tiled_kernel(AppendArgs A, int64_t S) {
   constexpr int N = Fmt<BITS>::kN;
   __shared__ __attribute__((aligned(16))) TiledShared sh;
   const int tid = threadIdx.x;
@@ -220,15 +220,20 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
   const int per = (C + kTG - 1) / kTG;            // <= kTE
   const int c0 = tg * per;
   float sel[kTE];
-  uint32_t key[kTE];
   bool ok[kTE];
 #pragma unroll
   for (int e = 0; e < kTE; e++) {
     ok[e] = e < per && (c0 + e) < C;
     const int c = ok[e] ? c0 + e : 0;
     sel[e] = ok[e] ? sh.ss[gt_][c + (c >> 5)] : 0.f;
-    key[e] = fkey(sel[e]);
   }
+  // The selection keys are recomputed from the values wherever they are needed (two instructions each) instead of living
+  // next to them through the whole phase: 16 registers of a kernel that is at the limit for three workgroups per CU.  The
+  // empty asm makes the values opaque between the uses, so that the compiler does not merge the recomputations again.
+  auto forget_keys = [&]() {
+#pragma unroll
+    for (int e = 0; e < kTE; e++) asm volatile("" : "+v"(sel[e]));
+  };
   uint32_t T[2], gtc[2];
   const uint32_t ksel = IS_V ? (uint32_t)(thr_k + 1) : (uint32_t)thr_k;
   uint32_t eq_hi = 0, eq_lo = 0;
@@ -236,9 +241,15 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
   if constexpr (KVQ_FAST_SELECT != 0) {
     // pruning select (kvq_select.h; round 6): three barriers instead of the radix chain's nine, no histogram atomics
     FselShared &fs = reinterpret_cast<FselShared &>(ts.hist);
-    fsel_bounds<kTE>(key, ok, ksel, kTG / 64, tg >> 6, ts.fctl);
-    __syncthreads();
-    fsel_collect<kTE>(key, ok, kTG / 64, fs, ts.fctl);
+    {
+      uint32_t key[kTE];
+#pragma unroll
+      for (int e = 0; e < kTE; e++) key[e] = fkey(sel[e]);
+      fsel_bounds<kTE>(key, ok, ksel, kTG / 64, tg >> 6, ts.fctl);
+      __syncthreads();
+      fsel_collect<kTE>(key, ok, kTG / 64, fs, ts.fctl);
+    }
+    forget_keys();
     __syncthreads();
     if (tg < 128) {
       if (!fsel_resolve(tg >> 6, ksel, fs, ts.fctl)) sh.fallback = 1;
@@ -251,7 +262,11 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
     }
   }
   if (radix) {
+    uint32_t key[kTE];
+#pragma unroll
+    for (int e = 0; e < kTE; e++) key[e] = fkey(sel[e]);
     group_select_both(key, ok, ksel, ts, tg, T, gtc);
+    forget_keys();
     // membership: strictly beyond the threshold, plus the first ties in channel order (fused_append_body)
 #pragma unroll
     for (int q = 0; q < kTHC; q++) {
@@ -269,25 +284,32 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
 #pragma unroll
     for (int e = 0; e < kTE; e++) {
       if (!ok[e]) continue;
-      ntie_hi += key[e] == T[0];
-      ntie_lo += key[e] == T[1];
+      const uint32_t ke = fkey(sel[e]);
+      ntie_hi += ke == T[0];
+      ntie_lo += ke == T[1];
     }
+    forget_keys();
     uint32_t tot;
     const uint32_t packed = group_excl_scan(ntie_hi | (ntie_lo << 16), ts.scan, tg, tot);
     rank_hi = packed & 0xffffu;
     rank_lo = packed >> 16;
   }
-  bool in_hi[kTE], in_lo[kTE];
+  // (membership as per-lane bit masks -- bit e = element e -- instead of 2 x 16 predicates: those live in scalar register
+  //  pairs, 64 of the ~100 a wave has, and spilled into vector registers once the V code search wanted its midpoints there)
+  uint32_t m_hi = 0, m_lo = 0;
   uint32_t nsel = 0;
 #pragma unroll
   for (int e = 0; e < kTE; e++) {
-    in_hi[e] = in_lo[e] = false;
     if (!ok[e]) continue;
-    if (key[e] > T[0]) in_hi[e] = true;
-    else if (key[e] == T[0]) { in_hi[e] = rank_hi < want_hi; rank_hi++; }
-    if (key[e] < T[1]) in_lo[e] = true;
-    else if (key[e] == T[1]) { in_lo[e] = rank_lo < want_lo; rank_lo++; }
-    nsel += (in_hi[e] || in_lo[e]);
+    bool ih = false, il = false;
+    const uint32_t ke = fkey(sel[e]);
+    if (ke > T[0]) ih = true;
+    else if (ke == T[0]) { ih = rank_hi < want_hi; rank_hi++; }
+    if (ke < T[1]) il = true;
+    else if (ke == T[1]) { il = rank_lo < want_lo; rank_lo++; }
+    m_hi |= ih ? (1u << e) : 0u;
+    m_lo |= il ? (1u << e) : 0u;
+    nsel += (ih || il);
   }
 
   float vmin = 0.f, vmax = 0.f, zpv = 0.f;
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
 #pragma unroll
     for (int e = 0; e < kTE; e++) {
       if (!ok[e]) continue;
-      const bool clip = A.tie_quirk ? (sel[e] < vmin || sel[e] > vmax) : (in_hi[e] || in_lo[e]);
+      const bool clip = A.tie_quirk ? (sel[e] < vmin || sel[e] > vmax) : ((((m_hi | m_lo) >> e) & 1u) != 0);
       const unsigned code = clip ? Fmt<BITS>::kZeroCode : nearest_code<N>(row, sel[e]);
       if (per == kTE) cw[e >> 2] |= code << (8 * (e & 3));
       else sh.cb[gt_][c0 + e] = (unsigned char)code;
@@ -345,16 +367,18 @@ __global__ __launch_bounds__(kTNT) void pack_tiled_kernel(AppendArgs A, int64_t 
   float *orow = A.outliers + col * n_out;
   int32_t *irow = A.outlier_idx + col * n_out;
   const float *xs_ = reinterpret_cast<const float *>(A.x) + s;
+  int c0_late = c0;
+  asm volatile("" : "+v"(c0_late));     // (the channel ids are re-derived here: kept from the top of the phase they were spilled)
 #pragma unroll
   for (int e = 0; e < kTE; e++) {
-    if (!ok[e] || !(in_hi[e] || in_lo[e])) continue;
-    const int c = c0 + e;
+    if (!ok[e] || !(((m_hi | m_lo) >> e) & 1u)) continue;
+    const int c = c0_late + e;
     float val;
     if constexpr (IS_V) {
       val = sel[e] - zpv;                                  // modeling_llama.py:1169
     } else {
       // residual to the saturated end point; zero when the rescaled value is inside [-1, 1] (ML:729-747)
-      if (in_hi[e]) val = (sel[e] <= 1.0f) ? 0.f : xs_[(int64_t)c * S] - A.lut_off[(int64_t)c * N + (N - 1)];
+      if ((m_hi >> e) & 1u) val = (sel[e] <= 1.0f) ? 0.f : xs_[(int64_t)c * S] - A.lut_off[(int64_t)c * N + (N - 1)];
       else val = (sel[e] >= -1.0f) ? 0.f : xs_[(int64_t)c * S] - A.lut_off[(int64_t)c * N];
     }
     if ((int)pos < n_out) {
