@@ -173,3 +173,44 @@ def test_k_append_and_pack_select_paths(bits):
             assert torch.equal(a[..., :S].view(torch.int32), b[..., :S].view(torch.int32))
         else:
             assert torch.equal(a[:S].view(torch.int32), b[:S].view(torch.int32))
+
+
+@pytest.mark.parametrize("Hs,k", [(3, 2), (8, 6), (5, 21), (40, 21)])
+def test_v_select_other_widths(Hs, k):
+    """hidden sizes other than 4096: waves of the selection group that hold no keys publish no bound (everything is a
+    candidate: short lists are searched as they are, long ones go to the radix select), C > 4096 takes the per-token pack"""
+    from kvquant_amd import ops
+    from kvquant_amd.cache import ZERO_CODE
+    bits = 4
+    dev = torch.device("cuda:0")
+    Cs = Hs * HD
+    g = torch.Generator().manual_seed(Hs * 100 + k)
+    S, max_len = 8, 64
+    xs = (torch.randn(S, Cs, generator=g) * 2).half().float()
+    xs[1, : Cs // 2] = 3.25                     # a long run of ties through the cut
+    xs[2] = 0.5                                 # all equal
+    lut_sorted = util.centroids(bits).to(dev)
+    W = HD // 32 * bits
+    mat = torch.zeros(Hs, W, max_len, dtype=torch.int32, device=dev)
+    rows = torch.zeros(max_len, 2 ** bits, device=dev)
+    ov, oi = torch.zeros(max_len, 2 * k, device=dev), torch.zeros(max_len, 2 * k, dtype=torch.int32, device=dev)
+    for t in range(S):
+        ops.append_v_fused(bits, mat, rows, lut_sorted, xs[t].to(dev), ov, oi, k, t)
+    torch.cuda.synchronize()
+    for t in range(S):
+        x = xs[t]
+        hi, lo = spec_select(x, k), spec_select(-x, k)
+        if set(hi.tolist()) & set(lo.tolist()):
+            continue
+        uv, lv = torch.sort(x, descending=True).values[k], torch.sort(x).values[k]
+        want_rows = util.centroids(bits) * ((uv - lv) / 2) + (uv + lv) / 2
+        assert torch.equal(rows[t].cpu().view(torch.int32), want_rows.view(torch.int32)), t
+        want_i = torch.sort(torch.cat((hi, lo))).values
+        assert torch.equal(oi[t].long().cpu(), want_i), t
+        assert torch.equal(ov[t].cpu().view(torch.int32), (x[want_i] - want_rows[ZERO_CODE[bits]]).view(torch.int32)), t
+    mat2, rows2, ov2, oi2 = torch.zeros_like(mat), torch.zeros_like(rows), torch.zeros_like(ov), torch.zeros_like(oi)
+    ops.pack_v_fused(bits, mat2, rows2, lut_sorted, xs.t().contiguous().view(Hs, HD, S).to(dev), ov2, oi2, k, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(mat2[:, :, :S], mat[:, :, :S])
+    assert torch.equal(rows2[:S].view(torch.int32), rows[:S].view(torch.int32))
+    assert torch.equal(ov2[:S].view(torch.int32), ov[:S].view(torch.int32)) and torch.equal(oi2[:S], oi[:S])
