@@ -43,13 +43,17 @@ class _Shadow:
     __slots__ = ("ref_o", "ref_i", "ptr_o", "ptr_i", "shape", "length", "ver_o", "ver_i", "stream", "out_t", "idx_t")
 
 
-def _shadow_mirror(outliers, outlier_indices, L):
-    """the shadow mirror of (outliers, outlier_indices) with columns [0, L) current; None = use the row kernel"""
+def _shadow_mirror(outliers, outlier_indices, L, stream=None, transpose=None):
+    """the shadow mirror of (outliers, outlier_indices) with columns [0, L) current; None = use the row kernel.
+    (stream / transpose: the host-logic tests pass a stream id and a recorder instead of the GPU's)"""
     max_len, n_out = outliers.shape
     if n_out * max_len * 4 >= 1 << 32:
         return None
     key = id(outliers)
-    stream = torch.cuda.current_stream(outliers.device).cuda_stream
+    if stream is None:
+        stream = torch.cuda.current_stream(outliers.device).cuda_stream
+    if transpose is None:
+        transpose = ops.outlier_mirror_rows
     s = _shadow.get(key)
     fresh = (s is None or s.ref_o() is not outliers or s.ref_i() is not outlier_indices or
              s.ptr_o != outliers.data_ptr() or s.ptr_i != outlier_indices.data_ptr() or
@@ -70,7 +74,7 @@ def _shadow_mirror(outliers, outlier_indices, L):
         # (a call at an unchanged length is re-transposed too: a writer that bypasses torch -- a custom kernel -- leaves no
         #  trace in the counters, and a second score over the same cache is not what the reference's decode loop does)
         t0 = s.length if (grown >= 1 and d_o == grown and d_i == grown) else 0
-    ops.outlier_mirror_rows(outliers, outlier_indices, s.out_t, s.idx_t, t0, L)
+    transpose(outliers, outlier_indices, s.out_t, s.idx_t, t0, L)
     shadow_stats["full" if t0 == 0 else "incremental"] += 1
     s.length, s.ver_o, s.ver_i = L, outliers._version, outlier_indices._version
     return s

@@ -62,3 +62,66 @@ def test_bench_event_sampling_covers_all_layers():
     assert every >= 1 and math.gcd(every, 32) == 1
     timed = {(c % 32) for c in range(1, 32 * every + 1) if c % every == 0}
     assert timed == set(range(32))
+
+
+def test_quant_cuda_shadow_mirror_decisions():
+    """which rows kvquant_amd.quant_cuda transposes into its shadow mirror before an `_opt2` call: one
+    row after the reference glue's append (one in-place write per array, ML:748-749), everything whenever older rows may
+    have changed.  Host logic only: CPU tensors, a recorder instead of the transposing launch."""
+    import gc
+    import torch
+    from kvquant_amd import quant_cuda as qc
+    calls = []
+
+    def rec(o, i, ot, it, t0, t1):
+        assert tuple(ot.shape) == (o.shape[1], o.shape[0]) and ot.dtype == torch.float32 and it.dtype == torch.int32
+        calls.append((t0, t1))
+
+    def step(o, i, L, stream=7):
+        calls.clear()
+        s = qc._shadow_mirror(o, i, L, stream=stream, transpose=rec)
+        assert s is not None and s.length == L
+        return calls[0]
+
+    qc.shadow_invalidate()
+    vals, idx = torch.zeros(64, 6), torch.zeros(64, 6, dtype=torch.int32)
+    assert step(vals, idx, 10) == (0, 10)                     # first call: everything
+    vals[10] = 1.0
+    idx[10] = 3
+    assert step(vals, idx, 11) == (10, 11)                    # the glue's append: one row
+    vals[11] = 2.0
+    idx[11] = 4
+    vals[12] = 2.0
+    idx[12] = 4
+    assert step(vals, idx, 13) == (11, 13)                    # two appends between two calls: two rows
+    vals[3] = 9.0                                             # an older row rewritten + an append: the counters moved by 2
+    vals[13] = 1.0
+    idx[13] = 1
+    assert step(vals, idx, 14) == (0, 14)
+    assert step(vals, idx, 14) == (0, 14)                     # the same length again
+    assert step(vals, idx, 5) == (0, 5)                       # a shorter cache (reset)
+    vals[5:9] = 1.0                                           # a prompt: many rows, ONE in-place write per array
+    idx[5:9] = 2
+    assert step(vals, idx, 9) == (0, 9)
+    vals[9] = 1.0                                             # only ONE of the two arrays written
+    assert step(vals, idx, 10) == (0, 10)
+    vals[10] = 1.0
+    idx[10] = 1
+    assert step(vals, idx, 11, stream=8) == (0, 11)           # another stream
+    vals[11] = 1.0
+    idx[11] = 1
+    assert step(vals, idx, 12, stream=8) == (11, 12)
+    idx2 = idx.clone()                                        # another index tensor
+    vals[12] = 1.0
+    idx2[12] = 1
+    assert step(vals, idx2, 13, stream=8) == (0, 13)
+    vals[13] = 1.0
+    idx2[13] = 1
+    qc.shadow_invalidate(vals)                                # the documented way out for writers torch does not see
+    assert step(vals, idx2, 14, stream=8) == (0, 14)
+    # the entry dies with the tensor
+    n0 = len(qc._shadow)
+    del vals
+    gc.collect()
+    assert len(qc._shadow) == n0 - 1
+    qc.shadow_invalidate()
