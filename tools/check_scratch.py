@@ -18,8 +18,9 @@ ARCH = os.environ.get("KVQ_ARCH", "gfx950")
 
 # (regex on the demangled-ish kernel name, why scratch is tolerated there)
 ALLOWED = [
-    (r"score_k_kernelILi\dELb1ELi8ELb0ELb0ELi0E", "row-layout sparse score kernel of the LEGACY quant_cuda entry points "
-                                                  "(decode_kv reads the token-contiguous mirror): 3-5 VGPRs outside the head loop"),
+    (r"score_k_kernelILi\dELb1ELi8ELb0ELb0ELi0E", "row-layout sparse score kernel behind kvq_score_k with the reference's outlier rows "
+                                                  "(q_len > 1, direct C callers; decode_kv and, from 16K tokens, quant_cuda's _opt2 read a "
+                                                  "token-contiguous mirror instead): 4-7 VGPRs outside the head loop"),
     (r"fused_decode_kernelILi2E", "fused attend at 2 bit (opt-in route, never a default)"),
 ]
 
